@@ -1,0 +1,200 @@
+/* tango_hip.h -- C ABI of libtango_hip.so: batched fp64 HIP kernels (gfx950) for Tango's
+ * implicit transport inner loop.
+ *
+ * The reference (sundials-codes/tango) is pure Python and has no FFI on this path: its boundary is
+ * Python call signatures on 1-D float64 NumPy arrays.  Each entry point below names the reference
+ * function(s) it replaces; the Python package tango_amd/ binds them with ctypes and keeps the
+ * reference's signatures.
+ *
+ * Conventions
+ *  - every array argument is a DEVICE pointer to float64 unless the name ends in _host;
+ *  - nb = number of independent profiles, n = number of radial grid points;
+ *  - layout TG_POINT_FASTEST stores profile b, point j at X[b*n + j] (a C-contiguous (nb, n) array);
+ *    TG_BATCH_FASTEST stores it at X[j*nb + b] (profiles interleaved so that a lane-per-profile
+ *    sweep is coalesced).  Entry points without a layout argument are point-fastest;
+ *  - "shared or per-profile" coefficient arrays come with a stride in elements: 0 = one (n,) array
+ *    used by every profile, n = an (nb, n) array;
+ *  - nothing here allocates or frees device memory except tg_malloc/tg_free; work space is passed in;
+ *  - every call is asynchronous on `stream` (a hipStream_t; NULL = the default stream);
+ *  - return value: TG_OK or an error code; tg_last_error() gives the message of the calling thread.
+ */
+#ifndef TANGO_HIP_H
+#define TANGO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *tg_stream;
+
+enum { TG_OK = 0, TG_ERR_ARG = 1, TG_ERR_HIP = 2, TG_ERR_UNSUPPORTED = 3 };
+enum { TG_POINT_FASTEST = 0, TG_BATCH_FASTEST = 1 };
+
+/* per-profile status bits written by the solvers */
+enum {
+    TG_ST_CONVERGED = 1, /* residual dropped below tol (tango/solver.py:472-475) */
+    TG_ST_INVALID = 2,   /* NaN, Inf or negative value in a new profile (tango/solver.py:420-439) */
+    TG_ST_SINGULAR = 4,  /* zero pivot met (scipy raises LinAlgError on it) */
+    TG_ST_SEEDED = 8     /* the EWMA memories hold a previous iterate (tango/lodestro_method.py:706-708) */
+};
+
+/* ---- library / device / memory plumbing (no reference counterpart) ------------------------- */
+int tg_version(void);
+const char *tg_last_error(void);
+int tg_device_count(int *count);
+int tg_set_device(int device);
+int tg_malloc(void **ptr, size_t bytes);
+int tg_free(void *ptr);
+int tg_memset(void *ptr, int value, size_t bytes, tg_stream stream);
+int tg_copy_h2d(void *dst, const void *src_host, size_t bytes, tg_stream stream);
+int tg_copy_d2h(void *dst_host, const void *src, size_t bytes, tg_stream stream);
+int tg_copy_d2d(void *dst, const void *src, size_t bytes, tg_stream stream);
+int tg_stream_create(tg_stream *stream);
+int tg_stream_destroy(tg_stream stream);
+int tg_stream_sync(tg_stream stream);
+
+/* ---- tridiagonal solve: tango/tridiag.py:12-31 (solve), :88-97 (solve_with_scipy -> dgtsv) ---
+ * C_j u_{j-1} + B_j u_j + A_j u_{j+1} = D_j, j = 0..n-1; A[n-1] and C[0] are ignored (LAPACK's band
+ * storage never reads them).  u may alias D.
+ *  - point-fastest: one wavefront (or one workgroup when n > 512) per profile, chunked elimination +
+ *    parallel cyclic reduction across lanes; no work space needed (work may be NULL);
+ *  - batch-fastest: one lane per profile, Thomas sweeps; needs tg_tridiag_work_bytes() of work space
+ *    for the forward-sweep multipliers.
+ * status: optional (nb,) int32, TG_ST_SINGULAR is OR-ed in for a profile that met a zero pivot. */
+size_t tg_tridiag_work_bytes(int64_t nb, int64_t n, int layout);
+int tg_tridiag_solve(const double *A, const double *B, const double *C, const double *D, double *u,
+                     int64_t nb, int64_t n, int layout, int32_t *status, void *work,
+                     size_t work_bytes, tg_stream stream);
+
+/* ---- finite-difference assembly: tango/HToMatrixFD.py:53-117 (H_to_matrix), :268-299 (_fbeta);
+ *      coupling column tango/JK_to_matrix_fd.py:119-130 (_H8_contribution) ------------------------
+ * H1 is required; H2,H3,H4,H6,H7,H8 may be NULL (= absent).  hs[k] is the stride of Hk as above
+ * (index 0..7 for H1..H8, slot of the non-existent H5 unused).  UL is (nb,); dt_b is an optional
+ * (nb,) per-profile timestep overriding dt.  G (optional output) = -H8 with 0 on the last row. */
+typedef struct {
+    const double *H1, *H2, *H3, *H4, *H6, *H7, *H8;
+    int64_t s1, s2, s3, s4, s6, s7, s8;
+} tg_hcoeffs;
+int tg_h_to_matrix(double dt, const double *dt_b, double dx, const double *UL,
+                   const double *U_mminus1, const tg_hcoeffs *H, double *A, double *B, double *C,
+                   double *D, double *G, int64_t nb, int64_t n, tg_stream stream);
+
+/* ---- residual: tango/fieldgroups.py:122-144, :226-256; rms of tango/solver.py:464-470 ----------
+ * r = (A u_{j+1} + B u_j + C u_{j-1} [+ G w_j] - f) / max_j|f_j|.  resid (nb,n) and sumsq (nb,) are
+ * optional outputs; sumsq[b] = sum_j r_j^2 (the caller forms sqrt(sum over fields / total length)). */
+int tg_residual(const double *A, const double *B, const double *C, const double *f, const double *u,
+                const double *G, const double *w, double *resid, double *sumsq, int64_t nb,
+                int64_t n, tg_stream stream);
+
+/* ---- LoDestro pieces: tango/lodestro_method.py:682-728 (EWMA), :563-679 (FluxSplit),
+ *      tango/derivatives.py:9-41, tango/smoother.py:13-48,
+ *      tango/extras/shestakov_nonlinear_diffusion.py:51-61 ------------------------------------- */
+int tg_ewma(const double *y, double *y_ewma_inout, double param, int seeded, int64_t count,
+            tg_stream stream);
+/* gxx/gradx: optional (n,) shared arrays (NULL = 1).  DHat, cHat, theta: optional outputs. */
+int tg_flux_split(const double *flux, const double *p, double dx, double Dmin, double Dmax,
+                  double dpdx_thr, const double *gxx, const double *gradx, double *D, double *c,
+                  double *DHat, double *cHat, double *theta, int64_t nb, int64_t n,
+                  tg_stream stream);
+/* edge_order 1: two-point one-sided ends; 2: three-point second-order ends */
+int tg_ddx(const double *u, double dx, int edge_order, double *out, int64_t nb, int64_t n,
+           tg_stream stream);
+/* window must be odd (callers add one to even windows as the reference's Smoother does) */
+int tg_moving_average(const double *x, int window, double *out, int64_t nb, int64_t n,
+                      tg_stream stream);
+/* Gamma = -(dn/dx)^3 / n^2 */
+int tg_shestakov_flux(const double *nprof, double dx, double *flux, int64_t nb, int64_t n,
+                      tg_stream stream);
+
+/* ---- pair-coupled solve: tango/JK_to_matrix_fd.py:132-166 (interleaved 5-band dgbsv) -----------
+ * C^U U_{j-1} + B^U U_j + A^U U_{j+1} + G^W W_j = D^U and the same with U<->W; solved as a
+ * block-tridiagonal system with 2x2 blocks [[BU,GW],[GU,BW]] and diagonal off-diagonal blocks. */
+int tg_pair_solve(const double *AU, const double *BU, const double *CU, const double *DU,
+                  const double *GW, const double *AW, const double *BW, const double *CW,
+                  const double *DW, const double *GU, double *U, double *W, int64_t nb, int64_t n,
+                  int32_t *status, tg_stream stream);
+
+/* ---- 3x3 block-tridiagonal solve (superset of the reference's n + (pi,pe) structure) -----------
+ * Row j: Cb_j x_{j-1} + Bb_j x_j + Ab_j x_{j+1} = d_j with 3x3 blocks.  Blocks are stored
+ * component-major: Bb[(r*3+c)*nb*n + b*n + j]; d and x: [r*nb*n + b*n + j]. */
+int tg_block3_solve(const double *Cb, const double *Bb, const double *Ab, const double *d, double *x,
+                    int64_t nb, int64_t n, int32_t *status, tg_stream stream);
+
+/* ---- fused Picard iteration, one field --------------------------------------------------------
+ * One call = one pass of tango/solver.py:188-272 (compute_next_iteration) for every active profile of
+ * the ensemble with the analytic flux built in: EWMA(profile) -> flux -> [smoothing] -> FluxSplit ->
+ * EWMA(D), EWMA(c) -> H2,H3 -> H_to_matrix -> residual of the current profile -> tridiagonal solve ->
+ * validity check.  State arrays are (nb, n) point-fastest and stay resident on the device. */
+typedef struct {
+    int64_t nb, n;
+    double *u;         /* current profile, overwritten with the new iterate */
+    const double *um1; /* profile of the previous timestep (tango/multifield.py:18) */
+    double *uE;        /* EWMA memory of the profile */
+    double *DE, *cE;   /* EWMA memories of D and c */
+    int32_t *status;   /* (nb,) TG_ST_* bits */
+    int32_t *iters;    /* (nb,) iterations performed so far (column of err to write next) */
+    double *err;       /* (nb, err_stride) rms residual history, or NULL */
+    int64_t err_stride;
+} tg_state_1f;
+
+enum { TG_FLUX_SHESTAKOV = 0, TG_FLUX_EXTERNAL = 1 };
+
+typedef struct {
+    double dt, dx;
+    double a_turb, a_prof;       /* EWMA parameters (tango/lodestro_method.py:417) */
+    double Dmin, Dmax, dpdx_thr; /* thetaParams (tango/lodestro_method.py:664-666) */
+    double tol;
+    const double *UL;    /* (nb,) right boundary values */
+    const double *dt_b;  /* optional (nb,) per-profile pseudo-timestep */
+    const double *H1;    /* optional (n,) shared; NULL = 1 */
+    const double *H7;    /* optional source array, stride h7_stride; NULL = S0*[x<delta] */
+    int64_t h7_stride;
+    const double *S0, *delta; /* (nb,) source parameters used when H7 == NULL */
+    const double *x;          /* optional (n,) grid; NULL = j*dx */
+    const double *Vprime, *gxx, *gradx;    /* optional (n,) geometry on the transport grid */
+    const double *gxx_turb, *gradx_turb;   /* optional (n,) geometry used by the flux split */
+    const double *flux;  /* (nb,n) flux when flux_model == TG_FLUX_EXTERNAL (profile EWMA already advanced) */
+    int32_t flux_model;
+    int32_t smooth_window; /* odd; 1 = no smoothing */
+    int32_t fixed_count;   /* nonzero: step every profile regardless of its status, never mark converged */
+    int32_t frozen_turb;   /* nonzero: reuse DE,cE as they are (inner iteration, tango/solver.py:274-309) */
+} tg_params_1f;
+
+int tg_picard_1f_step(const tg_state_1f *state, const tg_params_1f *params, tg_stream stream);
+
+/* counts[0..3] (device int64): profiles still active, converged, invalid, singular;
+ * maxrms (device double): largest last residual among all profiles (NULL to skip). */
+int tg_status_reduce(const int32_t *status, int64_t nb, int64_t *counts, tg_stream stream);
+
+/* ---- fused Picard iteration, three fields n, pi<->pe -------------------------------------------
+ * examples/shestakov_threefield_nonlinearnu.py:52-149 on the same call stack: shared D = (dpi/dx)^2/pi^2
+ * for the three fluxes, sources S_n = 8[x<.3], S_i = [x<.1], S_e = 3x[x<.4], collisional coupling
+ * nu = nu0/((pi+pe)/n)^{3/2} as H6 = -nu, H8 = +nu; n solved as a scalar tridiagonal system and
+ * (pi,pe) as a 2x2 block-tridiagonal one (tango/fieldgroups.py:275-331). */
+typedef struct {
+    int64_t nb, n;
+    double *u[3];          /* n, pi, pe */
+    const double *um1[3];
+    double *uE[3], *DE[3], *cE[3];
+    int32_t *status, *iters;
+    double *err;
+    int64_t err_stride;
+} tg_state_3f;
+
+typedef struct {
+    double dt, dx, a_turb, a_prof, Dmin, Dmax, dpdx_thr, tol;
+    const double *UL[3]; /* (nb,) each */
+    const double *nu0;   /* (nb,) */
+    int32_t fixed_count;
+    int32_t frozen_turb;
+} tg_params_3f;
+
+int tg_picard_3f_step(const tg_state_3f *state, const tg_params_3f *params, tg_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TANGO_HIP_H */

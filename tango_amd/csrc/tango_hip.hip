@@ -1,0 +1,709 @@
+// libtango_hip.so -- batched fp64 kernels for Tango's implicit transport inner loop, written for
+// MI355X (gfx950: 64-wide wavefronts, 256 CUs, HBM-bound fp64 stencil + tridiagonal work; no MFMA,
+// nothing on this path is a dense contraction).  The C ABI is declared in include/tango_hip.h.
+//
+// Data layout.  Persistent state is point-fastest, X[b*n + j]: a profile is a contiguous row, so
+// one wavefront streams one profile with full-line accesses and every array is read and written
+// exactly once per Picard iteration.  A wavefront (n <= 512) or a workgroup (n <= 16384) owns a
+// profile; each lane keeps P = 8 consecutive grid points in registers from the first load to the
+// last store: the forward-sweep intermediates of the tridiagonal solve never touch memory.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/tango_hip.h"
+#include "tg_assemble.h"
+#include "tg_comm.h"
+#include "tg_solve.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *a = "") {
+    snprintf(g_err, sizeof(g_err), fmt, a);
+    return code;
+}
+
+#define TG_HIP(call)                                                        \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) return fail(TG_ERR_HIP, #call ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+inline hipStream_t S(tg_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+int launch_check() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(TG_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return TG_OK;
+}
+
+using namespace tg;
+
+// ------------------------------------------------------------------------------------------
+// Row I/O: lane t of a group reads / writes its P consecutive points of a profile row.
+// ------------------------------------------------------------------------------------------
+template <int P>
+__device__ __forceinline__ void load_chunk(const double *__restrict__ row, int n, int j0, double *v, double fill) {
+    if constexpr (P % 2 == 0) {
+        if (j0 + P <= n && ((reinterpret_cast<uintptr_t>(row + j0) & 15) == 0)) {
+            const double2 *q = reinterpret_cast<const double2 *>(row + j0);
+#pragma unroll
+            for (int i = 0; i < P / 2; ++i) {
+                double2 w = q[i];
+                v[2 * i] = w.x;
+                v[2 * i + 1] = w.y;
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) v[i] = (j0 + i < n) ? row[j0 + i] : fill;
+}
+
+template <int P>
+__device__ __forceinline__ void store_chunk(double *__restrict__ row, int n, int j0, const double *v) {
+    if constexpr (P % 2 == 0) {
+        if (j0 + P <= n && ((reinterpret_cast<uintptr_t>(row + j0) & 15) == 0)) {
+            double2 *q = reinterpret_cast<double2 *>(row + j0);
+#pragma unroll
+            for (int i = 0; i < P / 2; ++i) q[i] = make_double2(v[2 * i], v[2 * i + 1]);
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+        if (j0 + i < n) row[j0 + i] = v[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Tridiagonal solve, point-fastest: one lane group per profile.
+// ------------------------------------------------------------------------------------------
+template <int P, class G>
+__global__ void __launch_bounds__(G::kBlock ? G::T : 256)
+tridiag_pf_kernel(const double *__restrict__ A, const double *__restrict__ B, const double *__restrict__ C,
+                  const double *__restrict__ D, double *__restrict__ u, int64_t nb, int n,
+                  int32_t *__restrict__ status) {
+    extern __shared__ double lds[];
+    G g(lds);
+    const int64_t b = (int64_t)blockIdx.x * G::profiles_per_block(blockDim.x) + g.profile_in_block();
+    if (b >= nb) return;
+    const int j0 = g.t() * P;
+    const int64_t off = b * (int64_t)n;
+    double a[P], bb[P], c[P], d[P];
+    load_chunk<P>(A + off, n, j0, a, 0.0);
+    load_chunk<P>(B + off, n, j0, bb, 1.0);
+    load_chunk<P>(C + off, n, j0, c, 0.0);
+    load_chunk<P>(D + off, n, j0, d, 0.0);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        if (j0 + i == 0) c[i] = 0.0;
+        if (j0 + i == n - 1) a[i] = 0.0;
+    }
+    int sing = 0;
+    chunk_solve<P>(g, c, bb, a, d, sing);
+    store_chunk<P>(u + off, n, j0, d);
+    if (status) {
+        sing = g.any(sing);
+        if (sing && g.t() == 0) atomicOr(&status[b], TG_ST_SINGULAR);
+    }
+}
+
+// Tridiagonal solve, batch-fastest: one lane per profile, every access of a sweep coalesced across
+// the batch.  cp (n*nb) holds the forward-sweep multipliers; the modified right-hand side is kept
+// in u and overwritten by the back substitution.
+__global__ void __launch_bounds__(256)
+tridiag_bf_kernel(const double *__restrict__ A, const double *__restrict__ B, const double *__restrict__ C,
+                  const double *__restrict__ D, double *u, int64_t nb, int n, double *__restrict__ cp,
+                  int32_t *__restrict__ status) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    int sing = 0;
+    double den = B[b];
+    sing |= (den == 0.0);
+    double e = (n > 1 ? A[b] : 0.0) / den;
+    double f = D[b] / den;
+    cp[b] = e;
+    u[b] = f;
+    // software prefetch of the next row keeps several loads in flight per lane
+    for (int j = 1; j < n; ++j) {
+        const int64_t k = (int64_t)j * nb + b;
+        const double cj = C[k], bj = B[k], dj = D[k];
+        const double aj = (j < n - 1) ? A[k] : 0.0;
+        den = bj - cj * e;
+        sing |= (den == 0.0);
+        e = aj / den;
+        f = (dj - cj * f) / den;
+        cp[k] = e;
+        u[k] = f;
+    }
+    double x = f;
+    for (int j = n - 2; j >= 0; --j) {
+        const int64_t k = (int64_t)j * nb + b;
+        x = u[k] - cp[k] * x;
+        u[k] = x;
+    }
+    if (status && sing) atomicOr(&status[b], TG_ST_SINGULAR);
+}
+
+// ------------------------------------------------------------------------------------------
+// Element-wise / stencil kernels on (nb, n) point-fastest arrays: one thread per point.
+// ------------------------------------------------------------------------------------------
+__global__ void ewma_kernel(const double *__restrict__ y, double *__restrict__ ye, double a, int seeded, int64_t count) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) {
+        const double v = y[i];
+        ye[i] = seeded ? a * v + (1.0 - a) * ye[i] : a * v + (1.0 - a) * v;
+    }
+}
+
+__global__ void ddx_kernel(const double *__restrict__ u, double dx, int order, double *__restrict__ out, int64_t nb, int n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = nb * n, stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int j = (int)(i % n);
+        const double *r = u + (i - j);
+        double v;
+        if (order == 2 && j == 0) v = (-3.0 / 2.0 * r[0] + 2.0 * r[1] - 1.0 / 2.0 * r[2]) / dx;
+        else if (order == 2 && j == n - 1) v = (3.0 / 2.0 * r[n - 1] - 2.0 * r[n - 2] + 1.0 / 2.0 * r[n - 3]) / dx;
+        else v = ddx_edge1_point(j > 0 ? r[j - 1] : 0.0, r[j], j < n - 1 ? r[j + 1] : 0.0, j, n, dx);
+        out[i] = v;
+    }
+}
+
+__global__ void shestakov_flux_kernel(const double *__restrict__ p, double dx, double *__restrict__ out, int64_t nb, int n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = nb * n, stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int j = (int)(i % n);
+        const double *r = p + (i - j);
+        const double d = ddx_edge1_point(j > 0 ? r[j - 1] : 0.0, r[j], j < n - 1 ? r[j + 1] : 0.0, j, n, dx);
+        out[i] = -(d * d * d) / (r[j] * r[j]);
+    }
+}
+
+__global__ void flux_split_kernel(const double *__restrict__ flux, const double *__restrict__ p, double dx, Theta th,
+                                  const double *__restrict__ gxx, const double *__restrict__ gradx,
+                                  double *__restrict__ D, double *__restrict__ c, double *__restrict__ DHat,
+                                  double *__restrict__ cHat, double *__restrict__ theta, int64_t nb, int n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = nb * n, stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int j = (int)(i % n);
+        const double *r = p + (i - j);
+        const double dpdx = ddx_edge1_point(j > 0 ? r[j - 1] : 0.0, r[j], j < n - 1 ? r[j + 1] : 0.0, j, n, dx);
+        double Dv, cv, DH, cH, thv;
+        flux_split_point(flux[i], r[j], dpdx, gxx ? gxx[j] : 1.0, gradx ? gradx[j] : 1.0, th, Dv, cv, DH, cH, thv);
+        D[i] = Dv;
+        c[i] = cv;
+        if (DHat) DHat[i] = DH;
+        if (cHat) cHat[i] = cH;
+        if (theta) theta[i] = thv;
+    }
+}
+
+// Centred moving average (tango/smoother.py:13-48): full window w in the interior, the symmetric
+// window 2j+1 on the (w-1)/2 points at either end.  Summed directly, left to right.
+__global__ void moving_average_kernel(const double *__restrict__ x, int w, double *__restrict__ out, int64_t nb, int n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = nb * n, stride = (int64_t)gridDim.x * blockDim.x;
+    const int h = (w - 1) / 2;
+    for (; i < total; i += stride) {
+        const int j = (int)(i % n);
+        const double *r = x + (i - j);
+        int hh = h;
+        if (j < hh) hh = j;
+        if (n - 1 - j < hh) hh = n - 1 - j;
+        double s = 0.0;
+        for (int k = j - hh; k <= j + hh; ++k) s += r[k];
+        out[i] = s / (double)(2 * hh + 1);
+    }
+}
+
+struct HC {
+    tg_hcoeffs h;
+};
+
+__device__ __forceinline__ double hval(const double *H, int64_t stride, int64_t b, int j) {
+    return H[b * stride + j];
+}
+
+__global__ void h_to_matrix_kernel(double dt, const double *__restrict__ dt_b, double dx, const double *__restrict__ UL,
+                                   const double *__restrict__ Um1, HC hc, double *__restrict__ A, double *__restrict__ B,
+                                   double *__restrict__ C, double *__restrict__ D, double *__restrict__ G, int64_t nb, int n) {
+    const tg_hcoeffs &H = hc.h;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = nb * n, stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int j = (int)(i % n);
+        const int64_t b = i / n;
+        const double dtv = dt_b ? dt_b[b] : dt;
+        double h2m = 0, h3m = 0, bm = 0, h2p = 0, h3p = 0, bp = 0, g4 = 0, h6 = 0, h7 = 0;
+        if (j < n - 1) {
+            if (H.H2) {
+                h2p = (hval(H.H2, H.s2, b, j) + hval(H.H2, H.s2, b, j + 1)) / 2.0;
+                if (j > 0) h2m = (hval(H.H2, H.s2, b, j - 1) + hval(H.H2, H.s2, b, j)) / 2.0;
+            }
+            if (H.H3) {
+                h3p = (hval(H.H3, H.s3, b, j) + hval(H.H3, H.s3, b, j + 1)) / 2.0;
+                bp = fbeta_point(h2p, h3p, dx);
+                if (j > 0) {
+                    h3m = (hval(H.H3, H.s3, b, j - 1) + hval(H.H3, H.s3, b, j)) / 2.0;
+                    bm = fbeta_point(h2m, h3m, dx);
+                }
+            }
+            if (H.H4) {
+                if (j == 0) g4 = -(hval(H.H4, H.s4, b, 0) + hval(H.H4, H.s4, b, 1)) / (2.0 * dx);
+                else g4 = -(hval(H.H4, H.s4, b, j + 1) - hval(H.H4, H.s4, b, j - 1)) / (2.0 * dx);
+            }
+            if (H.H6) h6 = hval(H.H6, H.s6, b, j);
+            if (H.H7) h7 = hval(H.H7, H.s7, b, j);
+        }
+        double a_, b_, c_, d_;
+        fd_row(j, n, hval(H.H1, H.s1, b, j), Um1[i], dtv, dx, UL[b], h2m, h3m, bm, h2p, h3p, bp, g4, h6, h7, a_, b_, c_, d_);
+        A[i] = a_;
+        B[i] = b_;
+        C[i] = c_;
+        D[i] = d_;
+        if (G) G[i] = (H.H8 && j < n - 1) ? -hval(H.H8, H.s8, b, j) : 0.0;
+    }
+}
+
+// Residual: one lane group of 64 lanes per profile (any n), strided over the row.
+__global__ void __launch_bounds__(256)
+residual_kernel(const double *__restrict__ A, const double *__restrict__ B, const double *__restrict__ C,
+                const double *__restrict__ f, const double *__restrict__ u, const double *__restrict__ G,
+                const double *__restrict__ w, double *__restrict__ resid, double *__restrict__ sumsq, int64_t nb, int n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= nb) return;
+    const int64_t off = b * (int64_t)n;
+    double mx = 0.0;
+    for (int j = lane; j < n; j += 64) mx = fmax(mx, fabs(f[off + j]));
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
+    double ss = 0.0;
+    for (int j = lane; j < n; j += 64) {
+        const double up = (j < n - 1) ? u[off + j + 1] : 0.0;
+        const double um = (j > 0) ? u[off + j - 1] : 0.0;
+        double r = A[off + j] * up + B[off + j] * u[off + j] + C[off + j] * um;
+        if (G) r = r + G[off + j] * w[off + j];
+        r = r - f[off + j];
+        r = r / mx;
+        if (resid) resid[off + j] = r;
+        ss += r * r;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) ss += __shfl_xor(ss, m, 64);
+    if (sumsq && lane == 0) sumsq[b] = ss;
+}
+
+__global__ void status_reduce_kernel(const int32_t *__restrict__ status, int64_t nb, unsigned long long *counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long act = 0, conv = 0, inv = 0, sing = 0;
+    for (; i < nb; i += stride) {
+        const int s = status[i];
+        conv += (s & TG_ST_CONVERGED) != 0;
+        inv += (s & TG_ST_INVALID) != 0;
+        sing += (s & TG_ST_SINGULAR) != 0;
+        act += (s & (TG_ST_CONVERGED | TG_ST_INVALID)) == 0;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        act += __shfl_xor(act, m, 64);
+        conv += __shfl_xor(conv, m, 64);
+        inv += __shfl_xor(inv, m, 64);
+        sing += __shfl_xor(sing, m, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (act) atomicAdd(&counts[0], act);
+        if (conv) atomicAdd(&counts[1], conv);
+        if (inv) atomicAdd(&counts[2], inv);
+        if (sing) atomicAdd(&counts[3], sing);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused Picard iteration, one field.
+// ------------------------------------------------------------------------------------------
+template <int P, class G>
+__global__ void __launch_bounds__(G::kBlock ? G::T : 256)
+picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
+    extern __shared__ double lds[];
+    G g(lds);
+    const int64_t b = (int64_t)blockIdx.x * G::profiles_per_block(blockDim.x) + g.profile_in_block();
+    if (b >= S_.nb) return;
+    const int st = S_.status[b];
+    if (!Q.fixed_count && (st & (TG_ST_CONVERGED | TG_ST_INVALID))) return;
+    const bool seeded = (st & TG_ST_SEEDED) != 0;
+    const int n = (int)S_.n;
+    const int j0 = g.t() * P;
+    const int64_t off = b * S_.n;
+    const double dx = Q.dx;
+    const double dt = Q.dt_b ? Q.dt_b[b] : Q.dt;
+    const double UL = Q.UL[b];
+
+    double u[P + 2], DE[P], cE[P];
+    load_chunk<P>(S_.u + off, n, j0, u + 1, 0.0);
+    if (!Q.frozen_turb) {
+        double ue[P + 2];
+        if (Q.flux_model == TG_FLUX_EXTERNAL) {
+            load_chunk<P>(S_.uE + off, n, j0, ue + 1, 1.0);
+        } else {
+            load_chunk<P>(S_.uE + off, n, j0, ue + 1, 1.0);
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const double prev = seeded ? ue[i + 1] : u[i + 1];
+                ue[i + 1] = Q.a_prof * u[i + 1] + (1.0 - Q.a_prof) * prev;
+            }
+            store_chunk<P>(S_.uE + off, n, j0, ue + 1);
+        }
+        ue[0] = g.from_left(ue[P], 1, 0.0);
+        ue[P + 1] = g.from_right(ue[1], 1, 0.0);
+        double fl[P];
+        if (Q.flux_model == TG_FLUX_EXTERNAL) load_chunk<P>(Q.flux + off, n, j0, fl, 0.0);
+        load_chunk<P>(S_.DE + off, n, j0, DE, 0.0);
+        load_chunk<P>(S_.cE + off, n, j0, cE, 0.0);
+        const Theta th{Q.Dmin, Q.Dmax, Q.dpdx_thr};
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int j = j0 + i;
+            const int jc = j < n ? j : n - 1;
+            const double dpdx = ddx_edge1_point(ue[i], ue[i + 1], ue[i + 2], j, n, dx);
+            const double p = ue[i + 1];
+            const double flux = (Q.flux_model == TG_FLUX_EXTERNAL) ? fl[i] : -(dpdx * dpdx * dpdx) / (p * p);
+            double D, c, DH, cH, thv;
+            flux_split_point(flux, p, dpdx, Q.gxx_turb ? Q.gxx_turb[jc] : 1.0, Q.gradx_turb ? Q.gradx_turb[jc] : 1.0, th, D,
+                             c, DH, cH, thv);
+            DE[i] = Q.a_turb * D + (1.0 - Q.a_turb) * (seeded ? DE[i] : D);
+            cE[i] = Q.a_turb * c + (1.0 - Q.a_turb) * (seeded ? cE[i] : c);
+        }
+        store_chunk<P>(S_.DE + off, n, j0, DE);
+        store_chunk<P>(S_.cE + off, n, j0, cE);
+    } else {
+        load_chunk<P>(S_.DE + off, n, j0, DE, 0.0);
+        load_chunk<P>(S_.cE + off, n, j0, cE, 0.0);
+    }
+
+    // H2, H3 on the integer grid with one halo point on each side (tango/lodestro_method.py:400-405)
+    double h2[P + 2], h3[P + 2];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int j = j0 + i;
+        if (Q.Vprime) {
+            const int jc = j < n ? j : n - 1;
+            const double vp = Q.Vprime[jc];
+            h2[i + 1] = vp * DE[i] * (Q.gxx ? Q.gxx[jc] : 1.0);
+            h3[i + 1] = -vp * cE[i] * (Q.gradx ? Q.gradx[jc] : 1.0);
+        } else {
+            h2[i + 1] = DE[i];
+            h3[i + 1] = -cE[i];
+        }
+    }
+    h2[0] = g.from_left(h2[P], 1, 0.0);
+    h3[0] = g.from_left(h3[P], 1, 0.0);
+    h2[P + 1] = g.from_right(h2[1], 1, 0.0);
+    h3[P + 1] = g.from_right(h3[1], 1, 0.0);
+    u[0] = g.from_left(u[P], 1, 0.0);
+    u[P + 1] = g.from_right(u[1], 1, 0.0);
+
+    // half-grid values: slot k is the point between local indices k-1 and k
+    double hh2[P + 1], hh3[P + 1], bet[P + 1];
+#pragma unroll
+    for (int k = 0; k <= P; ++k) {
+        hh2[k] = (h2[k] + h2[k + 1]) / 2.0;
+        hh3[k] = (h3[k] + h3[k + 1]) / 2.0;
+        bet[k] = fbeta_point(hh2[k], hh3[k], dx);
+    }
+
+    double um1[P];
+    load_chunk<P>(S_.um1 + off, n, j0, um1, 0.0);
+    const double S0 = Q.H7 ? 0.0 : Q.S0[b];
+    const double delta = Q.H7 ? 0.0 : Q.delta[b];
+    double A[P], B[P], C[P], f[P];
+    double mx = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int j = j0 + i;
+        if (j < n) {
+            const double H1 = Q.H1 ? Q.H1[j] : 1.0;
+            double h7;
+            if (Q.H7) h7 = Q.H7[b * Q.h7_stride + j];
+            else {
+                const double x = Q.x ? Q.x[j] : (double)j * dx;
+                h7 = (x < delta) ? S0 : 0.0;
+            }
+            fd_row(j, n, H1, um1[i], dt, dx, UL, hh2[i], hh3[i], bet[i], hh2[i + 1], hh3[i + 1], bet[i + 1], 0.0, 0.0, h7,
+                   A[i], B[i], C[i], f[i]);
+            mx = fmax(mx, fabs(f[i]));
+        } else {
+            A[i] = 0.0; B[i] = 1.0; C[i] = 0.0; f[i] = 0.0;
+        }
+    }
+    mx = g.max(mx);
+    // residual of the current profile with the new matrix (tango/fieldgroups.py:139-140)
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        if (j0 + i < n) {
+            double r = A[i] * u[i + 2] + B[i] * u[i + 1] + C[i] * u[i] - f[i];
+            r = r / mx;
+            ss += r * r;
+        }
+    }
+    ss = g.sum(ss);
+    const double rms = sqrt(1.0 / (double)n * ss);
+
+    int sing = 0;
+    chunk_solve<P>(g, C, B, A, f, sing);
+    int bad = 0;
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+        if (j0 + i < n) bad |= !(isfinite(f[i]) && f[i] >= 0.0);
+    store_chunk<P>(S_.u + off, n, j0, f);
+    bad = g.any(bad);
+    sing = g.any(sing);
+    if (g.t() == 0) {
+        const int it = S_.iters[b];
+        if (S_.err && it < S_.err_stride) S_.err[b * S_.err_stride + it] = rms;
+        S_.iters[b] = it + 1;
+        int ns = st;
+        if (!Q.frozen_turb) ns |= TG_ST_SEEDED;
+        if (!Q.fixed_count && rms < Q.tol) ns |= TG_ST_CONVERGED;
+        if (bad) ns |= TG_ST_INVALID;
+        if (sing) ns |= TG_ST_SINGULAR;
+        S_.status[b] = ns;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Launch geometry: lanes per profile for a grid of n points at P points per lane.
+// ------------------------------------------------------------------------------------------
+int pow2_at_least(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int grid_1d(int64_t total, int block) {
+    int64_t g = (total + block - 1) / block;
+    const int64_t cap = 256 * 32;  // CUs x resident blocks; grid-stride beyond that
+    return (int)(g < cap ? (g > 0 ? g : 1) : cap);
+}
+
+template <template <int, class> class Launcher, class... Args>
+int dispatch_group(int64_t nb, int n, hipStream_t s, Args... args) {
+    constexpr int P = 8;
+    const int lanes = pow2_at_least((n + P - 1) / P);
+    if (lanes <= 8) return Launcher<P, WaveGroup<8>>::go(nb, n, s, args...);
+    if (lanes == 16) return Launcher<P, WaveGroup<16>>::go(nb, n, s, args...);
+    if (lanes == 32) return Launcher<P, WaveGroup<32>>::go(nb, n, s, args...);
+    if (lanes == 64) return Launcher<P, WaveGroup<64>>::go(nb, n, s, args...);
+    if (lanes == 128) return Launcher<P, BlockGroup<128>>::go(nb, n, s, args...);
+    if (lanes == 256) return Launcher<P, BlockGroup<256>>::go(nb, n, s, args...);
+    if (lanes == 512) return Launcher<P, BlockGroup<512>>::go(nb, n, s, args...);
+    if (lanes == 1024) return Launcher<P, BlockGroup<1024>>::go(nb, n, s, args...);
+    if (n <= 16384) return Launcher<16, BlockGroup<1024>>::go(nb, n, s, args...);
+    return fail(TG_ERR_UNSUPPORTED, "point-fastest solvers support n <= 16384%s");
+}
+
+template <class G>
+void geometry(int64_t nb, int &grid, int &block, size_t &lds) {
+    if (G::kBlock) {
+        block = G::T;
+        grid = (int)nb;
+        lds = sizeof(double) * 6 * G::T;
+    } else {
+        block = 256;
+        const int ppb = 256 / G::T;
+        grid = (int)((nb + ppb - 1) / ppb);
+        lds = 0;
+    }
+}
+
+template <int P, class G>
+struct TridiagLauncher {
+    static int go(int64_t nb, int n, hipStream_t s, const double *A, const double *B, const double *C, const double *D,
+                  double *u, int32_t *status) {
+        int grid, block;
+        size_t lds;
+        geometry<G>(nb, grid, block, lds);
+        hipLaunchKernelGGL((tridiag_pf_kernel<P, G>), dim3(grid), dim3(block), lds, s, A, B, C, D, u, nb, n, status);
+        return launch_check();
+    }
+};
+
+template <int P, class G>
+struct Picard1fLauncher {
+    static int go(int64_t nb, int n, hipStream_t s, const tg_state_1f *st, const tg_params_1f *q) {
+        int grid, block;
+        size_t lds;
+        geometry<G>(nb, grid, block, lds);
+        hipLaunchKernelGGL((picard_1f_kernel<P, G>), dim3(grid), dim3(block), lds, s, *st, *q);
+        return launch_check();
+    }
+};
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int tg_version(void) { return 100; }
+const char *tg_last_error(void) { return g_err; }
+
+int tg_device_count(int *count) {
+    if (!count) return fail(TG_ERR_ARG, "count is NULL%s");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(TG_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = c;
+    return TG_OK;
+}
+int tg_set_device(int device) { TG_HIP(hipSetDevice(device)); return TG_OK; }
+int tg_malloc(void **ptr, size_t bytes) {
+    if (!ptr) return fail(TG_ERR_ARG, "ptr is NULL%s");
+    TG_HIP(hipMalloc(ptr, bytes ? bytes : 8));
+    return TG_OK;
+}
+int tg_free(void *ptr) { TG_HIP(hipFree(ptr)); return TG_OK; }
+int tg_memset(void *ptr, int value, size_t bytes, tg_stream stream) { TG_HIP(hipMemsetAsync(ptr, value, bytes, S(stream))); return TG_OK; }
+int tg_copy_h2d(void *dst, const void *src, size_t bytes, tg_stream stream) { TG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream))); return TG_OK; }
+int tg_copy_d2h(void *dst, const void *src, size_t bytes, tg_stream stream) { TG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(stream))); return TG_OK; }
+int tg_copy_d2d(void *dst, const void *src, size_t bytes, tg_stream stream) { TG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(stream))); return TG_OK; }
+int tg_stream_create(tg_stream *stream) {
+    if (!stream) return fail(TG_ERR_ARG, "stream is NULL%s");
+    hipStream_t s;
+    TG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return TG_OK;
+}
+int tg_stream_destroy(tg_stream stream) { TG_HIP(hipStreamDestroy(S(stream))); return TG_OK; }
+int tg_stream_sync(tg_stream stream) { TG_HIP(hipStreamSynchronize(S(stream))); return TG_OK; }
+
+static int check_dims(int64_t nb, int64_t n, int64_t nmin) {
+    if (nb < 0 || n < nmin) return fail(TG_ERR_ARG, "bad dimensions (nb >= 0, n >= minimum for this operation)%s");
+    if (n > (int64_t)1 << 30) return fail(TG_ERR_ARG, "n too large%s");
+    return TG_OK;
+}
+
+size_t tg_tridiag_work_bytes(int64_t nb, int64_t n, int layout) {
+    return layout == TG_BATCH_FASTEST ? sizeof(double) * (size_t)nb * (size_t)n : 0;
+}
+
+int tg_tridiag_solve(const double *A, const double *B, const double *C, const double *D, double *u, int64_t nb, int64_t n,
+                     int layout, int32_t *status, void *work, size_t work_bytes, tg_stream stream) {
+    if (int e = check_dims(nb, n, 1)) return e;
+    if (!A || !B || !C || !D || !u) return fail(TG_ERR_ARG, "NULL array%s");
+    if (nb == 0) return TG_OK;
+    if (layout == TG_BATCH_FASTEST) {
+        if (!work || work_bytes < tg_tridiag_work_bytes(nb, n, layout)) return fail(TG_ERR_ARG, "work space too small%s");
+        hipLaunchKernelGGL(tridiag_bf_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, S(stream), A, B, C, D, u, nb,
+                           (int)n, (double *)work, status);
+        return launch_check();
+    }
+    if (layout != TG_POINT_FASTEST) return fail(TG_ERR_ARG, "unknown layout%s");
+    return dispatch_group<TridiagLauncher>(nb, (int)n, S(stream), A, B, C, D, u, status);
+}
+
+int tg_h_to_matrix(double dt, const double *dt_b, double dx, const double *UL, const double *U_mminus1, const tg_hcoeffs *H,
+                   double *A, double *B, double *C, double *D, double *G, int64_t nb, int64_t n, tg_stream stream) {
+    if (int e = check_dims(nb, n, 2)) return e;
+    if (!H || !H->H1) return fail(TG_ERR_ARG, "H1 is required%s");
+    if (!UL || !U_mminus1 || !A || !B || !C || !D) return fail(TG_ERR_ARG, "NULL array%s");
+    if (nb == 0) return TG_OK;
+    HC hc{*H};
+    hipLaunchKernelGGL(h_to_matrix_kernel, dim3(grid_1d(nb * n, 256)), dim3(256), 0, S(stream), dt, dt_b, dx, UL, U_mminus1, hc,
+                       A, B, C, D, G, nb, (int)n);
+    return launch_check();
+}
+
+int tg_residual(const double *A, const double *B, const double *C, const double *f, const double *u, const double *G,
+                const double *w, double *resid, double *sumsq, int64_t nb, int64_t n, tg_stream stream) {
+    if (int e = check_dims(nb, n, 1)) return e;
+    if (!A || !B || !C || !f || !u) return fail(TG_ERR_ARG, "NULL array%s");
+    if ((G != nullptr) != (w != nullptr)) return fail(TG_ERR_ARG, "G and w go together%s");
+    if (nb == 0) return TG_OK;
+    hipLaunchKernelGGL(residual_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, S(stream), A, B, C, f, u, G, w, resid,
+                       sumsq, nb, (int)n);
+    return launch_check();
+}
+
+int tg_ewma(const double *y, double *y_ewma_inout, double param, int seeded, int64_t count, tg_stream stream) {
+    if (count < 0 || !y || !y_ewma_inout) return fail(TG_ERR_ARG, "bad argument%s");
+    if (count == 0) return TG_OK;
+    hipLaunchKernelGGL(ewma_kernel, dim3(grid_1d(count, 256)), dim3(256), 0, S(stream), y, y_ewma_inout, param, seeded, count);
+    return launch_check();
+}
+
+int tg_flux_split(const double *flux, const double *p, double dx, double Dmin, double Dmax, double dpdx_thr, const double *gxx,
+                  const double *gradx, double *D, double *c, double *DHat, double *cHat, double *theta, int64_t nb, int64_t n,
+                  tg_stream stream) {
+    if (int e = check_dims(nb, n, 2)) return e;
+    if (!flux || !p || !D || !c) return fail(TG_ERR_ARG, "NULL array%s");
+    if (nb == 0) return TG_OK;
+    hipLaunchKernelGGL(flux_split_kernel, dim3(grid_1d(nb * n, 256)), dim3(256), 0, S(stream), flux, p, dx,
+                       Theta{Dmin, Dmax, dpdx_thr}, gxx, gradx, D, c, DHat, cHat, theta, nb, (int)n);
+    return launch_check();
+}
+
+int tg_ddx(const double *u, double dx, int edge_order, double *out, int64_t nb, int64_t n, tg_stream stream) {
+    if (int e = check_dims(nb, n, edge_order == 2 ? 3 : 2)) return e;
+    if (!u || !out || (edge_order != 1 && edge_order != 2)) return fail(TG_ERR_ARG, "bad argument%s");
+    if (nb == 0) return TG_OK;
+    hipLaunchKernelGGL(ddx_kernel, dim3(grid_1d(nb * n, 256)), dim3(256), 0, S(stream), u, dx, edge_order, out, nb, (int)n);
+    return launch_check();
+}
+
+int tg_moving_average(const double *x, int window, double *out, int64_t nb, int64_t n, tg_stream stream) {
+    if (int e = check_dims(nb, n, 1)) return e;
+    if (!x || !out || window < 1 || window % 2 == 0) return fail(TG_ERR_ARG, "window must be a positive odd integer%s");
+    if (window > n) return fail(TG_ERR_ARG, "window larger than the grid%s");
+    if (nb == 0) return TG_OK;
+    hipLaunchKernelGGL(moving_average_kernel, dim3(grid_1d(nb * n, 256)), dim3(256), 0, S(stream), x, window, out, nb, (int)n);
+    return launch_check();
+}
+
+int tg_shestakov_flux(const double *nprof, double dx, double *flux, int64_t nb, int64_t n, tg_stream stream) {
+    if (int e = check_dims(nb, n, 2)) return e;
+    if (!nprof || !flux) return fail(TG_ERR_ARG, "NULL array%s");
+    if (nb == 0) return TG_OK;
+    hipLaunchKernelGGL(shestakov_flux_kernel, dim3(grid_1d(nb * n, 256)), dim3(256), 0, S(stream), nprof, dx, flux, nb, (int)n);
+    return launch_check();
+}
+
+int tg_picard_1f_step(const tg_state_1f *st, const tg_params_1f *q, tg_stream stream) {
+    if (!st || !q) return fail(TG_ERR_ARG, "NULL state or params%s");
+    if (int e = check_dims(st->nb, st->n, 3)) return e;
+    if (!st->u || !st->um1 || !st->uE || !st->DE || !st->cE || !st->status || !st->iters) return fail(TG_ERR_ARG, "NULL state array%s");
+    if (!q->UL) return fail(TG_ERR_ARG, "UL is required%s");
+    if (!q->H7 && (!q->S0 || !q->delta)) return fail(TG_ERR_ARG, "either H7 or (S0, delta) is required%s");
+    if (q->flux_model == TG_FLUX_EXTERNAL && !q->flux) return fail(TG_ERR_ARG, "external flux model needs a flux array%s");
+    if (q->flux_model != TG_FLUX_EXTERNAL && q->flux_model != TG_FLUX_SHESTAKOV) return fail(TG_ERR_ARG, "unknown flux model%s");
+    if (q->smooth_window > 1) return fail(TG_ERR_UNSUPPORTED, "flux smoothing is not fused; smooth the flux with tg_moving_average and pass it as an external flux%s");
+    if (st->err && st->err_stride <= 0) return fail(TG_ERR_ARG, "err_stride must be positive%s");
+    if (st->nb == 0) return TG_OK;
+    return dispatch_group<Picard1fLauncher>(st->nb, (int)st->n, S(stream), st, q);
+}
+
+int tg_status_reduce(const int32_t *status, int64_t nb, int64_t *counts, tg_stream stream) {
+    if (!status || !counts || nb < 0) return fail(TG_ERR_ARG, "bad argument%s");
+    TG_HIP(hipMemsetAsync(counts, 0, 4 * sizeof(int64_t), S(stream)));
+    if (nb == 0) return TG_OK;
+    hipLaunchKernelGGL(status_reduce_kernel, dim3(grid_1d(nb, 256)), dim3(256), 0, S(stream), status, nb,
+                       reinterpret_cast<unsigned long long *>(counts));
+    return launch_check();
+}
+
+// Entry points of the coupled-field path are defined in tango_block.hip.
+
+}  // extern "C"

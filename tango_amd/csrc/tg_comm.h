@@ -1,0 +1,148 @@
+// Lane-group communication policies for the profile solvers (gfx950, 64-wide wavefronts).
+//
+// A profile is handled by a *group* of T cooperating lanes, lane t owning P contiguous grid
+// points.  Two group shapes exist:
+//   WaveGroup<LPP>  : T = LPP <= 64 lanes inside one wavefront (64/LPP profiles per wave); all
+//                     exchanges are cross-lane shuffles, no LDS and no barriers.
+//   BlockGroup<T>   : T = blockDim.x > 64 lanes = one workgroup per profile; exchanges go through
+//                     LDS with workgroup barriers.
+// Both expose the same interface so that the assembly and solve code is written once.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tg {
+
+template <int LPP>
+struct WaveGroup {
+    static constexpr int T = LPP;
+    static constexpr bool kBlock = false;
+    int t_;
+    __device__ explicit WaveGroup(double * /*lds*/) : t_(threadIdx.x & (LPP - 1)) {}
+    __device__ int t() const { return t_; }
+    // number of profiles handled by one workgroup of `threads` threads
+    static constexpr int profiles_per_block(int threads) { return threads / LPP; }
+    __device__ int64_t profile_in_block() const { return threadIdx.x / LPP; }
+
+    // value held by lane t-h (fill when there is none)
+    __device__ double from_left(double v, int h, double fill) const {
+        double r = __shfl_up(v, (unsigned)h, LPP);
+        return (t_ >= h) ? r : fill;
+    }
+    __device__ double from_right(double v, int h, double fill) const {
+        double r = __shfl_down(v, (unsigned)h, LPP);
+        return (t_ + h < LPP) ? r : fill;
+    }
+    __device__ double sum(double v) const {
+#pragma unroll
+        for (int m = LPP >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, LPP);
+        return v;
+    }
+    __device__ double max(double v) const {
+#pragma unroll
+        for (int m = LPP >> 1; m > 0; m >>= 1) v = fmax(v, __shfl_xor(v, m, LPP));
+        return v;
+    }
+    __device__ int any(int pred) const {
+#pragma unroll
+        for (int m = LPP >> 1; m > 0; m >>= 1) pred |= __shfl_xor(pred, m, LPP);
+        return pred;
+    }
+    // Parallel cyclic reduction of the unit-diagonal system s_t y_{t-1} + y_t + p_t y_{t+1} = r_t.
+    __device__ double pcr(double s, double p, double r, int &singular) const {
+#pragma unroll
+        for (int h = 1; h < LPP; h <<= 1) {
+            double sm = from_left(s, h, 0.0), pm = from_left(p, h, 0.0), rm = from_left(r, h, 0.0);
+            double sp = from_right(s, h, 0.0), pp = from_right(p, h, 0.0), rp = from_right(r, h, 0.0);
+            double g = 1.0 - pm * s - sp * p;
+            singular |= (g == 0.0);
+            double inv = 1.0 / g;
+            r = (r - rm * s - rp * p) * inv;
+            double s2 = -(sm * s) * inv;
+            double p2 = -(pp * p) * inv;
+            s = s2;
+            p = p2;
+        }
+        return r;
+    }
+};
+
+// One workgroup of T_ threads per profile.  `lds` must hold at least 6*T_ doubles.
+template <int T_>
+struct BlockGroup {
+    static constexpr int T = T_;
+    static constexpr bool kBlock = true;
+    double *lds_;
+    int t_;
+    __device__ explicit BlockGroup(double *lds) : lds_(lds), t_(threadIdx.x) {}
+    __device__ int t() const { return t_; }
+    static constexpr int profiles_per_block(int) { return 1; }
+    __device__ int64_t profile_in_block() const { return 0; }
+
+    __device__ double from_left(double v, int h, double fill) const {
+        lds_[t_] = v;
+        __syncthreads();
+        double r = (t_ >= h) ? lds_[t_ - h] : fill;
+        __syncthreads();
+        return r;
+    }
+    __device__ double from_right(double v, int h, double fill) const {
+        lds_[t_] = v;
+        __syncthreads();
+        double r = (t_ + h < T_) ? lds_[t_ + h] : fill;
+        __syncthreads();
+        return r;
+    }
+    __device__ double sum(double v) const {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((t_ & 63) == 0) lds_[t_ >> 6] = v;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < T_ / 64; ++w) tot += lds_[w];
+        __syncthreads();
+        return tot;
+    }
+    __device__ double max(double v) const {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+        if ((t_ & 63) == 0) lds_[t_ >> 6] = v;
+        __syncthreads();
+        double tot = lds_[0];
+#pragma unroll
+        for (int w = 1; w < T_ / 64; ++w) tot = fmax(tot, lds_[w]);
+        __syncthreads();
+        return tot;
+    }
+    __device__ int any(int pred) const { return __syncthreads_or(pred); }
+
+    __device__ double pcr(double s, double p, double r, int &singular) const {
+        // double-buffered rows in LDS: buffer k holds s,p,r at lds_[k*3*T_ + {0,1,2}*T_ + t]
+        int cur = 0;
+#pragma unroll 1
+        for (int h = 1; h < T_; h <<= 1) {
+            double *bs = lds_ + cur * 3 * T_, *bp = bs + T_, *br = bp + T_;
+            bs[t_] = s;
+            bp[t_] = p;
+            br[t_] = r;
+            __syncthreads();
+            double sm = 0.0, pm = 0.0, rm = 0.0, sp = 0.0, pp = 0.0, rp = 0.0;
+            if (t_ >= h) { sm = bs[t_ - h]; pm = bp[t_ - h]; rm = br[t_ - h]; }
+            if (t_ + h < T_) { sp = bs[t_ + h]; pp = bp[t_ + h]; rp = br[t_ + h]; }
+            double g = 1.0 - pm * s - sp * p;
+            singular |= (g == 0.0);
+            double inv = 1.0 / g;
+            r = (r - rm * s - rp * p) * inv;
+            double s2 = -(sm * s) * inv;
+            double p2 = -(pp * p) * inv;
+            s = s2;
+            p = p2;
+            cur ^= 1;
+        }
+        __syncthreads();
+        return r;
+    }
+};
+
+}  // namespace tg
