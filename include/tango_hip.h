@@ -56,6 +56,11 @@ int tg_stream_create(tg_stream *stream);
 int tg_stream_destroy(tg_stream stream);
 int tg_stream_sync(tg_stream stream);
 
+/* Streaming probe (no reference counterpart): out[k][i] = in[k][i] + in[k+1][i] over `count` doubles,
+ * five input and four output streams as in one fused one-field Picard step.  Used by the benchmark to
+ * measure the achievable HBM rate for that traffic shape on the device at hand. */
+int tg_stream_probe(const double *const in[5], double *const out[4], int64_t count, tg_stream stream);
+
 /* ---- tridiagonal solve: tango/tridiag.py:12-31 (solve), :88-97 (solve_with_scipy -> dgtsv) ---
  * C_j u_{j-1} + B_j u_j + A_j u_{j+1} = D_j, j = 0..n-1; A[n-1] and C[0] are ignored (LAPACK's band
  * storage never reads them).  u may alias D.

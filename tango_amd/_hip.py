@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libtango_hip.so')
+LIB_PATH = os.environ.get('TANGO_HIP_LIB') or os.path.join(_HERE, 'lib', 'libtango_hip.so')
 
 TG_OK, TG_ERR_ARG, TG_ERR_HIP, TG_ERR_UNSUPPORTED = 0, 1, 2, 3
 POINT_FASTEST, BATCH_FASTEST = 0, 1
@@ -80,6 +80,7 @@ PROTOTYPES = {
     'tg_stream_create': (_int, [C.POINTER(_p)]),
     'tg_stream_destroy': (_int, [_p]),
     'tg_stream_sync': (_int, [_p]),
+    'tg_stream_probe': (_int, [_p * 5, _p * 4, _i64, _p]),
     'tg_tridiag_work_bytes': (_sz, [_i64, _i64, _int]),
     'tg_tridiag_solve': (_int, [_p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _sz, _p]),
     'tg_h_to_matrix': (_int, [_dbl, _p, _dbl, _p, _p, C.POINTER(HCoeffsC), _p, _p, _p, _p, _p, _i64, _i64, _p]),

@@ -45,14 +45,22 @@ using namespace tg;
 // ------------------------------------------------------------------------------------------
 // Row I/O: lane t of a group reads / writes its P consecutive points of a profile row.
 // ------------------------------------------------------------------------------------------
-template <int P>
+// FULL: the row is exactly T*P points and 16-byte aligned (n even), so every lane takes the
+// vector path with no bounds checks.
+template <int P, bool FULL>
 __device__ __forceinline__ void load_chunk(const double *__restrict__ row, int n, int j0, double *v, double fill) {
     if constexpr (P % 2 == 0) {
-        if (j0 + P <= n && ((reinterpret_cast<uintptr_t>(row + j0) & 15) == 0)) {
+        if (FULL || (j0 + P <= n && ((reinterpret_cast<uintptr_t>(row + j0) & 15) == 0))) {
+#ifdef TG_EXPERIMENT_COALESCED
+            const double2 *q = reinterpret_cast<const double2 *>(row) + (threadIdx.x & 63);
+#define TG_QI(i) ((i) * 64)
+#else
             const double2 *q = reinterpret_cast<const double2 *>(row + j0);
+#define TG_QI(i) (i)
+#endif
 #pragma unroll
             for (int i = 0; i < P / 2; ++i) {
-                double2 w = q[i];
+                double2 w = q[TG_QI(i)];
                 v[2 * i] = w.x;
                 v[2 * i + 1] = w.y;
             }
@@ -63,13 +71,17 @@ __device__ __forceinline__ void load_chunk(const double *__restrict__ row, int n
     for (int i = 0; i < P; ++i) v[i] = (j0 + i < n) ? row[j0 + i] : fill;
 }
 
-template <int P>
+template <int P, bool FULL>
 __device__ __forceinline__ void store_chunk(double *__restrict__ row, int n, int j0, const double *v) {
     if constexpr (P % 2 == 0) {
-        if (j0 + P <= n && ((reinterpret_cast<uintptr_t>(row + j0) & 15) == 0)) {
+        if (FULL || (j0 + P <= n && ((reinterpret_cast<uintptr_t>(row + j0) & 15) == 0))) {
+#ifdef TG_EXPERIMENT_COALESCED
+            double2 *q = reinterpret_cast<double2 *>(row) + (threadIdx.x & 63);
+#else
             double2 *q = reinterpret_cast<double2 *>(row + j0);
+#endif
 #pragma unroll
-            for (int i = 0; i < P / 2; ++i) q[i] = make_double2(v[2 * i], v[2 * i + 1]);
+            for (int i = 0; i < P / 2; ++i) q[TG_QI(i)] = make_double2(v[2 * i], v[2 * i + 1]);
             return;
         }
     }
@@ -81,7 +93,7 @@ __device__ __forceinline__ void store_chunk(double *__restrict__ row, int n, int
 // ------------------------------------------------------------------------------------------
 // Tridiagonal solve, point-fastest: one lane group per profile.
 // ------------------------------------------------------------------------------------------
-template <int P, class G>
+template <int P, class G, bool FULL>
 __global__ void __launch_bounds__(G::kBlock ? G::T : 256)
 tridiag_pf_kernel(const double *__restrict__ A, const double *__restrict__ B, const double *__restrict__ C,
                   const double *__restrict__ D, double *__restrict__ u, int64_t nb, int n,
@@ -93,18 +105,18 @@ tridiag_pf_kernel(const double *__restrict__ A, const double *__restrict__ B, co
     const int j0 = g.t() * P;
     const int64_t off = b * (int64_t)n;
     double a[P], bb[P], c[P], d[P];
-    load_chunk<P>(A + off, n, j0, a, 0.0);
-    load_chunk<P>(B + off, n, j0, bb, 1.0);
-    load_chunk<P>(C + off, n, j0, c, 0.0);
-    load_chunk<P>(D + off, n, j0, d, 0.0);
+    load_chunk<P, FULL>(A + off, n, j0, a, 0.0);
+    load_chunk<P, FULL>(B + off, n, j0, bb, 1.0);
+    load_chunk<P, FULL>(C + off, n, j0, c, 0.0);
+    load_chunk<P, FULL>(D + off, n, j0, d, 0.0);
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        if (j0 + i == 0) c[i] = 0.0;
-        if (j0 + i == n - 1) a[i] = 0.0;
+        c[i] = (j0 + i == 0) ? 0.0 : c[i];
+        a[i] = (j0 + i == n - 1) ? 0.0 : a[i];
     }
     int sing = 0;
     chunk_solve<P>(g, c, bb, a, d, sing);
-    store_chunk<P>(u + off, n, j0, d);
+    store_chunk<P, FULL>(u + off, n, j0, d);
     if (status) {
         sing = g.any(sing);
         if (sing && g.t() == 0) atomicOr(&status[b], TG_ST_SINGULAR);
@@ -163,13 +175,14 @@ __global__ void ewma_kernel(const double *__restrict__ y, double *__restrict__ y
 __global__ void ddx_kernel(const double *__restrict__ u, double dx, int order, double *__restrict__ out, int64_t nb, int n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = nb * n, stride = (int64_t)gridDim.x * blockDim.x;
+    const Recip rc(dx, 1.0);
     for (; i < total; i += stride) {
         const int j = (int)(i % n);
         const double *r = u + (i - j);
         double v;
         if (order == 2 && j == 0) v = (-3.0 / 2.0 * r[0] + 2.0 * r[1] - 1.0 / 2.0 * r[2]) / dx;
         else if (order == 2 && j == n - 1) v = (3.0 / 2.0 * r[n - 1] - 2.0 * r[n - 2] + 1.0 / 2.0 * r[n - 3]) / dx;
-        else v = ddx_edge1_point(j > 0 ? r[j - 1] : 0.0, r[j], j < n - 1 ? r[j + 1] : 0.0, j, n, dx);
+        else v = ddx_edge1_point<true>(j > 0 ? r[j - 1] : 0.0, r[j], j < n - 1 ? r[j + 1] : 0.0, j == 0, j == n - 1, rc);
         out[i] = v;
     }
 }
@@ -177,10 +190,11 @@ __global__ void ddx_kernel(const double *__restrict__ u, double dx, int order, d
 __global__ void shestakov_flux_kernel(const double *__restrict__ p, double dx, double *__restrict__ out, int64_t nb, int n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = nb * n, stride = (int64_t)gridDim.x * blockDim.x;
+    const Recip rc(dx, 1.0);
     for (; i < total; i += stride) {
         const int j = (int)(i % n);
         const double *r = p + (i - j);
-        const double d = ddx_edge1_point(j > 0 ? r[j - 1] : 0.0, r[j], j < n - 1 ? r[j + 1] : 0.0, j, n, dx);
+        const double d = ddx_edge1_point<true>(j > 0 ? r[j - 1] : 0.0, r[j], j < n - 1 ? r[j + 1] : 0.0, j == 0, j == n - 1, rc);
         out[i] = -(d * d * d) / (r[j] * r[j]);
     }
 }
@@ -191,10 +205,11 @@ __global__ void flux_split_kernel(const double *__restrict__ flux, const double 
                                   double *__restrict__ cHat, double *__restrict__ theta, int64_t nb, int n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = nb * n, stride = (int64_t)gridDim.x * blockDim.x;
+    const Recip rc(dx, 1.0);
     for (; i < total; i += stride) {
         const int j = (int)(i % n);
         const double *r = p + (i - j);
-        const double dpdx = ddx_edge1_point(j > 0 ? r[j - 1] : 0.0, r[j], j < n - 1 ? r[j + 1] : 0.0, j, n, dx);
+        const double dpdx = ddx_edge1_point<true>(j > 0 ? r[j - 1] : 0.0, r[j], j < n - 1 ? r[j + 1] : 0.0, j == 0, j == n - 1, rc);
         double Dv, cv, DH, cH, thv;
         flux_split_point(flux[i], r[j], dpdx, gxx ? gxx[j] : 1.0, gradx ? gradx[j] : 1.0, th, Dv, cv, DH, cH, thv);
         D[i] = Dv;
@@ -240,7 +255,7 @@ __global__ void h_to_matrix_kernel(double dt, const double *__restrict__ dt_b, d
     for (; i < total; i += stride) {
         const int j = (int)(i % n);
         const int64_t b = i / n;
-        const double dtv = dt_b ? dt_b[b] : dt;
+        const Recip rc(dx, dt_b ? dt_b[b] : dt);
         double h2m = 0, h3m = 0, bm = 0, h2p = 0, h3p = 0, bp = 0, g4 = 0, h6 = 0, h7 = 0;
         if (j < n - 1) {
             if (H.H2) {
@@ -263,7 +278,7 @@ __global__ void h_to_matrix_kernel(double dt, const double *__restrict__ dt_b, d
             if (H.H7) h7 = hval(H.H7, H.s7, b, j);
         }
         double a_, b_, c_, d_;
-        fd_row(j, n, hval(H.H1, H.s1, b, j), Um1[i], dtv, dx, UL[b], h2m, h3m, bm, h2p, h3p, bp, g4, h6, h7, a_, b_, c_, d_);
+        fd_row<true>(j == n - 1, hval(H.H1, H.s1, b, j), Um1[i], rc, UL[b], h2m, h3m, bm, h2p, h3p, bp, g4, h6, h7, a_, b_, c_, d_);
         A[i] = a_;
         B[i] = b_;
         C[i] = c_;
@@ -301,6 +316,24 @@ residual_kernel(const double *__restrict__ A, const double *__restrict__ B, cons
     if (sumsq && lane == 0) sumsq[b] = ss;
 }
 
+// Streaming probe with the fused step's memory shape: five input streams, four output streams,
+// 16 bytes per lane, fully coalesced, no dependent arithmetic.  Its rate is the achievable ceiling
+// for the step's traffic on the device at hand.
+__global__ void __launch_bounds__(256)
+stream_probe_kernel(const double2 *__restrict__ a, const double2 *__restrict__ b, const double2 *__restrict__ c,
+                    const double2 *__restrict__ d, const double2 *__restrict__ e, double2 *__restrict__ w,
+                    double2 *__restrict__ x, double2 *__restrict__ y, double2 *__restrict__ z, int64_t n2) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n2; i += stride) {
+        const double2 va = a[i], vb = b[i], vc = c[i], vd = d[i], ve = e[i];
+        w[i] = make_double2(va.x + vb.x, va.y + vb.y);
+        x[i] = make_double2(vb.x + vc.x, vb.y + vc.y);
+        y[i] = make_double2(vc.x + vd.x, vc.y + vd.y);
+        z[i] = make_double2(vd.x + ve.x, vd.y + ve.y);
+    }
+}
+
 __global__ void status_reduce_kernel(const int32_t *__restrict__ status, int64_t nb, unsigned long long *counts) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -330,8 +363,11 @@ __global__ void status_reduce_kernel(const int32_t *__restrict__ status, int64_t
 // ------------------------------------------------------------------------------------------
 // Fused Picard iteration, one field.
 // ------------------------------------------------------------------------------------------
-template <int P, class G>
-__global__ void __launch_bounds__(G::kBlock ? G::T : 256)
+#ifndef TG_MINW
+#define TG_MINW 1
+#endif
+template <int P, class G, bool FULL>
+__global__ void __launch_bounds__(G::kBlock ? G::T : 256, G::kBlock ? 1 : TG_MINW)
 picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     extern __shared__ double lds[];
     G g(lds);
@@ -341,61 +377,66 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     if (!Q.fixed_count && (st & (TG_ST_CONVERGED | TG_ST_INVALID))) return;
     const bool seeded = (st & TG_ST_SEEDED) != 0;
     const int n = (int)S_.n;
-    const int j0 = g.t() * P;
+    const int t = g.t();
+    const int j0 = t * P;
     const int64_t off = b * S_.n;
-    const double dx = Q.dx;
-    const double dt = Q.dt_b ? Q.dt_b[b] : Q.dt;
+    const Recip rc(Q.dx, Q.dt_b ? Q.dt_b[b] : Q.dt);
     const double UL = Q.UL[b];
+    const bool lane_first = (t == 0);
+    // grids beyond one wavefront (n > 512) have condition numbers above 1e9: keep the reference's divisions
+    constexpr bool EXACT = G::kBlock;
 
-    double u[P + 2], DE[P], cE[P];
-    load_chunk<P>(S_.u + off, n, j0, u + 1, 0.0);
+    // issue every load of the profile up front
+    double u[P + 2], um1[P], DE[P], cE[P];
+    load_chunk<P, FULL>(S_.u + off, n, j0, u + 1, 0.0);
+    load_chunk<P, FULL>(S_.DE + off, n, j0, DE, 0.0);
+    load_chunk<P, FULL>(S_.cE + off, n, j0, cE, 0.0);
+    load_chunk<P, FULL>(S_.um1 + off, n, j0, um1, 0.0);
     if (!Q.frozen_turb) {
         double ue[P + 2];
+        load_chunk<P, FULL>(S_.uE + off, n, j0, ue + 1, 1.0);
+        double fl[P];
         if (Q.flux_model == TG_FLUX_EXTERNAL) {
-            load_chunk<P>(S_.uE + off, n, j0, ue + 1, 1.0);
+            load_chunk<P, FULL>(Q.flux + off, n, j0, fl, 0.0);
         } else {
-            load_chunk<P>(S_.uE + off, n, j0, ue + 1, 1.0);
+            // EWMA of the profile (tango/lodestro_method.py:345)
+            const double oma = 1.0 - Q.a_prof;
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-                const double prev = seeded ? ue[i + 1] : u[i + 1];
-                ue[i + 1] = Q.a_prof * u[i + 1] + (1.0 - Q.a_prof) * prev;
-            }
-            store_chunk<P>(S_.uE + off, n, j0, ue + 1);
+            for (int i = 0; i < P; ++i) ue[i + 1] = Q.a_prof * u[i + 1] + oma * (seeded ? ue[i + 1] : u[i + 1]);
+            store_chunk<P, FULL>(S_.uE + off, n, j0, ue + 1);
         }
         ue[0] = g.from_left(ue[P], 1, 0.0);
         ue[P + 1] = g.from_right(ue[1], 1, 0.0);
-        double fl[P];
-        if (Q.flux_model == TG_FLUX_EXTERNAL) load_chunk<P>(Q.flux + off, n, j0, fl, 0.0);
-        load_chunk<P>(S_.DE + off, n, j0, DE, 0.0);
-        load_chunk<P>(S_.cE + off, n, j0, cE, 0.0);
-        const Theta th{Q.Dmin, Q.Dmax, Q.dpdx_thr};
+        const Theta th(Q.Dmin, Q.Dmax, Q.dpdx_thr);
+        const double omt = 1.0 - Q.a_turb;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const int j = j0 + i;
-            const int jc = j < n ? j : n - 1;
-            const double dpdx = ddx_edge1_point(ue[i], ue[i + 1], ue[i + 2], j, n, dx);
+            const int jc = (FULL || j < n) ? j : n - 1;
+            const bool first = (i == 0) && lane_first;
+            const bool last = FULL ? (i == P - 1 && t == G::T - 1) : (j == n - 1);
+            const double dpdx = ddx_edge1_point<EXACT>(ue[i], ue[i + 1], ue[i + 2], first, last, rc);
             const double p = ue[i + 1];
+            // flux model (tango/extras/shestakov_nonlinear_diffusion.py:59-60)
             const double flux = (Q.flux_model == TG_FLUX_EXTERNAL) ? fl[i] : -(dpdx * dpdx * dpdx) / (p * p);
             double D, c, DH, cH, thv;
             flux_split_point(flux, p, dpdx, Q.gxx_turb ? Q.gxx_turb[jc] : 1.0, Q.gradx_turb ? Q.gradx_turb[jc] : 1.0, th, D,
                              c, DH, cH, thv);
-            DE[i] = Q.a_turb * D + (1.0 - Q.a_turb) * (seeded ? DE[i] : D);
-            cE[i] = Q.a_turb * c + (1.0 - Q.a_turb) * (seeded ? cE[i] : c);
+            // EWMA of D and c (tango/lodestro_method.py:368-369)
+            DE[i] = Q.a_turb * D + omt * (seeded ? DE[i] : D);
+            cE[i] = Q.a_turb * c + omt * (seeded ? cE[i] : c);
         }
-        store_chunk<P>(S_.DE + off, n, j0, DE);
-        store_chunk<P>(S_.cE + off, n, j0, cE);
-    } else {
-        load_chunk<P>(S_.DE + off, n, j0, DE, 0.0);
-        load_chunk<P>(S_.cE + off, n, j0, cE, 0.0);
+        store_chunk<P, FULL>(S_.DE + off, n, j0, DE);
+        store_chunk<P, FULL>(S_.cE + off, n, j0, cE);
     }
 
     // H2, H3 on the integer grid with one halo point on each side (tango/lodestro_method.py:400-405)
     double h2[P + 2], h3[P + 2];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        const int j = j0 + i;
         if (Q.Vprime) {
-            const int jc = j < n ? j : n - 1;
+            const int j = j0 + i;
+            const int jc = (FULL || j < n) ? j : n - 1;
             const double vp = Q.Vprime[jc];
             h2[i + 1] = vp * DE[i] * (Q.gxx ? Q.gxx[jc] : 1.0);
             h3[i + 1] = -vp * cE[i] * (Q.gradx ? Q.gradx[jc] : 1.0);
@@ -411,71 +452,70 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     u[0] = g.from_left(u[P], 1, 0.0);
     u[P + 1] = g.from_right(u[1], 1, 0.0);
 
-    // half-grid values: slot k is the point between local indices k-1 and k
-    double hh2[P + 1], hh3[P + 1], bet[P + 1];
-#pragma unroll
-    for (int k = 0; k <= P; ++k) {
-        hh2[k] = (h2[k] + h2[k + 1]) / 2.0;
-        hh3[k] = (h3[k] + h3[k + 1]) / 2.0;
-        bet[k] = fbeta_point(hh2[k], hh3[k], dx);
-    }
-
-    double um1[P];
-    load_chunk<P>(S_.um1 + off, n, j0, um1, 0.0);
     const double S0 = Q.H7 ? 0.0 : Q.S0[b];
     const double delta = Q.H7 ? 0.0 : Q.delta[b];
-    double A[P], B[P], C[P], f[P];
-    double mx = 0.0;
+
+    // Assemble row by row and eliminate at once.  Half-grid slot "m" lies between local points
+    // i-1 and i, slot "p" between i and i+1; the p values of row i are the m values of row i+1.
+    ChunkElim<P> el;
+    double hm2 = lane_first ? 0.0 : (h2[0] + h2[1]) / 2.0;
+    double hm3 = lane_first ? 0.0 : (h3[0] + h3[1]) / 2.0;
+    double bm = fbeta_point(hm2, hm3, rc.dx);
+    double mx = 0.0, ss = 0.0;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int j = j0 + i;
-        if (j < n) {
-            const double H1 = Q.H1 ? Q.H1[j] : 1.0;
-            double h7;
-            if (Q.H7) h7 = Q.H7[b * Q.h7_stride + j];
-            else {
-                const double x = Q.x ? Q.x[j] : (double)j * dx;
-                h7 = (x < delta) ? S0 : 0.0;
-            }
-            fd_row(j, n, H1, um1[i], dt, dx, UL, hh2[i], hh3[i], bet[i], hh2[i + 1], hh3[i + 1], bet[i + 1], 0.0, 0.0, h7,
-                   A[i], B[i], C[i], f[i]);
-            mx = fmax(mx, fabs(f[i]));
-        } else {
-            A[i] = 0.0; B[i] = 1.0; C[i] = 0.0; f[i] = 0.0;
+        const bool valid = FULL || (j < n);
+        const bool last = FULL ? (i == P - 1 && t == G::T - 1) : (j == n - 1);
+        const int jc = valid ? j : n - 1;
+        const double hp2 = (h2[i + 1] + h2[i + 2]) / 2.0;
+        const double hp3 = (h3[i + 1] + h3[i + 2]) / 2.0;
+        const double bp = fbeta_point(hp2, hp3, rc.dx);
+        const double H1 = Q.H1 ? Q.H1[jc] : 1.0;
+        double h7;
+        if (Q.H7) h7 = Q.H7[b * Q.h7_stride + jc];
+        else {
+            const double x = Q.x ? Q.x[jc] : (double)j * rc.dx;
+            h7 = (x < delta) ? S0 : 0.0;
         }
+        double A, B, C, f;
+        fd_row<EXACT>(last, H1, um1[i], rc, UL, hm2, hm3, bm, hp2, hp3, bp, 0.0, 0.0, h7, A, B, C, f);
+        if (!FULL) {
+            A = valid ? A : 0.0;
+            B = valid ? B : 1.0;
+            C = valid ? C : 0.0;
+            f = valid ? f : 0.0;
+        }
+        // residual of the current profile with the new matrix (tango/fieldgroups.py:139)
+        const double r = A * u[i + 2] + B * u[i + 1] + C * u[i] - f;
+        ss += valid ? r * r : 0.0;
+        mx = fmax(mx, valid ? fabs(f) : 0.0);
+        el.push(i, C, B, A, f);
+        hm2 = hp2;
+        hm3 = hp3;
+        bm = bp;
     }
+    // rms of r / max|f| (tango/fieldgroups.py:140, tango/solver.py:464-470)
     mx = g.max(mx);
-    // residual of the current profile with the new matrix (tango/fieldgroups.py:139-140)
-    double ss = 0.0;
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        if (j0 + i < n) {
-            double r = A[i] * u[i + 2] + B[i] * u[i + 1] + C[i] * u[i] - f[i];
-            r = r / mx;
-            ss += r * r;
-        }
-    }
     ss = g.sum(ss);
-    const double rms = sqrt(1.0 / (double)n * ss);
+    const double rms = sqrt(1.0 / (double)n * (ss / (mx * mx)));
 
-    int sing = 0;
-    chunk_solve<P>(g, C, B, A, f, sing);
+    double x[P];
+    el.finish(g, x);
     int bad = 0;
 #pragma unroll
-    for (int i = 0; i < P; ++i)
-        if (j0 + i < n) bad |= !(isfinite(f[i]) && f[i] >= 0.0);
-    store_chunk<P>(S_.u + off, n, j0, f);
-    bad = g.any(bad);
-    sing = g.any(sing);
-    if (g.t() == 0) {
+    for (int i = 0; i < P; ++i) bad |= (FULL || j0 + i < n) ? !(isfinite(x[i]) && x[i] >= 0.0) : 0;
+    store_chunk<P, FULL>(S_.u + off, n, j0, x);
+    bad = g.any(bad | (el.singular << 1));
+    if (t == 0) {
         const int it = S_.iters[b];
         if (S_.err && it < S_.err_stride) S_.err[b * S_.err_stride + it] = rms;
         S_.iters[b] = it + 1;
         int ns = st;
         if (!Q.frozen_turb) ns |= TG_ST_SEEDED;
         if (!Q.fixed_count && rms < Q.tol) ns |= TG_ST_CONVERGED;
-        if (bad) ns |= TG_ST_INVALID;
-        if (sing) ns |= TG_ST_SINGULAR;
+        if (bad & 1) ns |= TG_ST_INVALID;
+        if (bad & 2) ns |= TG_ST_SINGULAR;
         S_.status[b] = ns;
     }
 }
@@ -516,7 +556,7 @@ void geometry(int64_t nb, int &grid, int &block, size_t &lds) {
     if (G::kBlock) {
         block = G::T;
         grid = (int)nb;
-        lds = sizeof(double) * 6 * G::T;
+        lds = sizeof(double) * 8 * G::T;
     } else {
         block = 256;
         const int ppb = 256 / G::T;
@@ -532,7 +572,11 @@ struct TridiagLauncher {
         int grid, block;
         size_t lds;
         geometry<G>(nb, grid, block, lds);
-        hipLaunchKernelGGL((tridiag_pf_kernel<P, G>), dim3(grid), dim3(block), lds, s, A, B, C, D, u, nb, n, status);
+        const bool full = (n == P * G::T) && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) |
+                                                 reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(D) |
+                                                 reinterpret_cast<uintptr_t>(u)) & 15) == 0;
+        if (full) hipLaunchKernelGGL((tridiag_pf_kernel<P, G, true>), dim3(grid), dim3(block), lds, s, A, B, C, D, u, nb, n, status);
+        else hipLaunchKernelGGL((tridiag_pf_kernel<P, G, false>), dim3(grid), dim3(block), lds, s, A, B, C, D, u, nb, n, status);
         return launch_check();
     }
 };
@@ -543,7 +587,12 @@ struct Picard1fLauncher {
         int grid, block;
         size_t lds;
         geometry<G>(nb, grid, block, lds);
-        hipLaunchKernelGGL((picard_1f_kernel<P, G>), dim3(grid), dim3(block), lds, s, *st, *q);
+        uintptr_t al = reinterpret_cast<uintptr_t>(st->u) | reinterpret_cast<uintptr_t>(st->um1) |
+                       reinterpret_cast<uintptr_t>(st->uE) | reinterpret_cast<uintptr_t>(st->DE) |
+                       reinterpret_cast<uintptr_t>(st->cE) | reinterpret_cast<uintptr_t>(q->flux);
+        const bool full = (n == P * G::T) && (al & 15) == 0;
+        if (full) hipLaunchKernelGGL((picard_1f_kernel<P, G, true>), dim3(grid), dim3(block), lds, s, *st, *q);
+        else hipLaunchKernelGGL((picard_1f_kernel<P, G, false>), dim3(grid), dim3(block), lds, s, *st, *q);
         return launch_check();
     }
 };
@@ -652,7 +701,7 @@ int tg_flux_split(const double *flux, const double *p, double dx, double Dmin, d
     if (!flux || !p || !D || !c) return fail(TG_ERR_ARG, "NULL array%s");
     if (nb == 0) return TG_OK;
     hipLaunchKernelGGL(flux_split_kernel, dim3(grid_1d(nb * n, 256)), dim3(256), 0, S(stream), flux, p, dx,
-                       Theta{Dmin, Dmax, dpdx_thr}, gxx, gradx, D, c, DHat, cHat, theta, nb, (int)n);
+                       Theta(Dmin, Dmax, dpdx_thr), gxx, gradx, D, c, DHat, cHat, theta, nb, (int)n);
     return launch_check();
 }
 
@@ -693,6 +742,22 @@ int tg_picard_1f_step(const tg_state_1f *st, const tg_params_1f *q, tg_stream st
     if (st->err && st->err_stride <= 0) return fail(TG_ERR_ARG, "err_stride must be positive%s");
     if (st->nb == 0) return TG_OK;
     return dispatch_group<Picard1fLauncher>(st->nb, (int)st->n, S(stream), st, q);
+}
+
+int tg_stream_probe(const double *const in[5], double *const out[4], int64_t count, tg_stream stream) {
+    if (!in || !out || count < 0 || (count & 1)) return fail(TG_ERR_ARG, "count must be even and non-negative%s");
+    for (int k = 0; k < 5; ++k)
+        if (!in[k] || (reinterpret_cast<uintptr_t>(in[k]) & 15)) return fail(TG_ERR_ARG, "inputs must be 16-byte aligned%s");
+    for (int k = 0; k < 4; ++k)
+        if (!out[k] || (reinterpret_cast<uintptr_t>(out[k]) & 15)) return fail(TG_ERR_ARG, "outputs must be 16-byte aligned%s");
+    if (count == 0) return TG_OK;
+    const int64_t n2 = count / 2;
+    int64_t blocks = (n2 + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, S(stream), (const double2 *)in[0],
+                       (const double2 *)in[1], (const double2 *)in[2], (const double2 *)in[3], (const double2 *)in[4],
+                       (double2 *)out[0], (double2 *)out[1], (double2 *)out[2], (double2 *)out[3], n2);
+    return launch_check();
 }
 
 int tg_status_reduce(const int32_t *status, int64_t nb, int64_t *counts, tg_stream stream) {

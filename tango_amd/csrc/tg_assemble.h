@@ -1,86 +1,107 @@
 // Point-wise pieces of the LoDestro split and the finite-difference assembly, written once and
 // used by both the standalone kernels and the fused Picard kernels.  Each function states the
 // reference expression it evaluates; operations are kept in the reference's order.
+//
+// Divisions by quantities that are constant over a launch (dx, dx^2, 2dx, dt) can be done as
+// multiplications by a reciprocal formed once (an fp64 divide costs ~15 fp64 issue slots on gfx950 and
+// the assembly has nine of them per grid point).  That changes a coefficient by at most one ulp
+// relative to the reference's true division.  The template flag EXACT selects the true divisions: the
+// standalone kernels and the large-grid (n > 512, condition number > 1e9) fused path use them, the
+// wave-per-profile fused path uses reciprocals.  All branches are written as selects so that a lane's
+// eight points form one straight-line block the scheduler can interleave.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace tg {
 
+// x / d, either as the division itself (EXACT) or as x * (1/d) with the reciprocal formed once
+template <bool EXACT>
+__device__ __forceinline__ double cdiv(double x, double d, double inv) {
+    if constexpr (EXACT) return x / d;
+    else return x * inv;
+}
+
+// launch-constant divisors and their reciprocals
+struct Recip {
+    double dx, dx2, twodx, dt;
+    double idx, idx2, i2dx, idt;
+    __host__ __device__ Recip(double dx_, double dt_)
+        : dx(dx_), dx2(dx_ * dx_), twodx(2.0 * dx_), dt(dt_), idx(1.0 / dx_), idx2(1.0 / (dx_ * dx_)),
+          i2dx(1.0 / (2.0 * dx_)), idt(1.0 / dt_) {}
+};
+
 struct Theta {
-    double Dmin, Dmax, thr;
+    double Dmin, Dmax, thr, span;
+    __host__ __device__ Theta(double Dmin_, double Dmax_, double thr_)
+        : Dmin(Dmin_), Dmax(Dmax_), thr(thr_), span(Dmax_ - Dmin_) {}
 };
 
 // tango/lodestro_method.py:624-634 (DHat, cHat, D, c) with the default theta rule of :667-676.
 // gxx / gradx are the geometric factors on the turbulence grid (1 in Cartesian geometry).
+// NaN compares false everywhere, which leaves theta = 1 exactly as the reference's masks do.
 __device__ __forceinline__ void flux_split_point(double flux, double p, double dpdx, double gxx, double gradx,
                                                  const Theta &th, double &D, double &c, double &DHat,
                                                  double &cHat, double &theta) {
-    DHat = -flux / (gxx * dpdx);
-    if (dpdx == 0.0) DHat = 0.0;
+    double dh = -flux / (gxx * dpdx);
+    dh = (dpdx == 0.0) ? 0.0 : dh;
+    DHat = dh;
     cHat = flux / (gradx * p);
-    theta = 1.0;
-    if (DHat < th.Dmin) theta = 0.0;
     const bool small = fabs(dpdx) < th.thr;
-    if (small && DHat >= th.Dmin && DHat <= th.Dmax) theta = (1.0 + (th.Dmax - DHat) / (th.Dmax - th.Dmin)) / 2.0;
-    if (small && DHat > th.Dmax) theta = 0.5;
-    D = theta * DHat;
-    c = (1.0 - theta) * cHat;
+    // true division: c = (1-theta)*cHat cancels to ~1e-14 of theta's rounding, so theta must round as the reference's does
+    const double mid = (1.0 + (th.Dmax - dh) / th.span) / 2.0;
+    double tv = 1.0;
+    tv = (dh < th.Dmin) ? 0.0 : tv;
+    tv = (small && dh >= th.Dmin && dh <= th.Dmax) ? mid : tv;
+    tv = (small && dh > th.Dmax) ? 0.5 : tv;
+    theta = tv;
+    D = tv * dh;
+    c = (1.0 - tv) * cHat;
 }
 
 // tango/HToMatrixFD.py:277-297: adaptive upwinding weight at a half-integer grid point.
+// One division H2h/(c dx) serves both signs of c; the result is discarded where c == 0.
 __device__ __forceinline__ double fbeta_point(double H2h, double H3h, double dx) {
     const double gamma = 0.9;
     const double c = -H3h;
-    double beta = 0.0;
-    if (c > 0.0) {
-        double star = 1.0 - H2h / (c * dx);
-        if (star <= 0.5) beta = 0.5;
-        else if (star > 0.5) beta = gamma * star + (1.0 - gamma);
-    } else if (c < 0.0) {
-        double star = -H2h / (c * dx);
-        if (star >= 0.5) beta = 0.5;
-        else if (star < 0.5) beta = gamma * star;
-    }
-    return beta;
+    const double q = H2h / (c * dx);
+    const double sp = 1.0 - q;   // betaStar for c > 0
+    const double sn = -q;        // betaStar for c < 0
+    const double bp = (sp <= 0.5) ? 0.5 : ((sp > 0.5) ? gamma * sp + (1.0 - gamma) : 0.0);
+    const double bn = (sn >= 0.5) ? 0.5 : ((sn < 0.5) ? gamma * sn : 0.0);
+    return (c > 0.0) ? bp : ((c < 0.0) ? bn : 0.0);
 }
 
 // tango/derivatives.py:20-24: centred difference with two-point one-sided ends.
-// um, u0, up are the values at j-1, j, j+1 (um unused at j = 0, up unused at j = n-1).
-__device__ __forceinline__ double ddx_edge1_point(double um, double u0, double up, int j, int n, double dx) {
-    if (j == 0) return (up - u0) / dx;
-    if (j == n - 1) return (u0 - um) / dx;
-    return (up - um) / (2.0 * dx);
+// um, u0, up are the values at j-1, j, j+1 (um unused at the first point, up at the last).
+template <bool EXACT>
+__device__ __forceinline__ double ddx_edge1_point(double um, double u0, double up, bool first, bool last,
+                                                  const Recip &rc) {
+    const double num = first ? (up - u0) : (last ? (u0 - um) : (up - um));
+    if constexpr (EXACT) return num / ((first || last) ? rc.dx : rc.twodx);
+    else return num * ((first || last) ? rc.idx : rc.i2dx);
 }
 
 // One row of tango/HToMatrixFD.py:87-117 accumulated in the order H1, H2, H3, H4, H6, H7, boundary.
-// h2m/h3m/bm: H2, H3, beta at j-1/2; h2p/h3p/bp at j+1/2.  g4 is the H4 term already formed
-// (-(H4_{j+1}-H4_{j-1})/(2dx), or -(H4_0+H4_1)/(2dx) at j = 0; 0 when H4 is absent); h6, h7 are
-// 0 when absent.  Returns A (super), B (diag), C (sub) and the right-hand side D = -g.
-__device__ __forceinline__ void fd_row(int j, int n, double H1, double Um1, double dt, double dx, double UL,
-                                       double h2m, double h3m, double bm, double h2p, double h3p, double bp,
-                                       double g4, double h6, double h7, double &A, double &B, double &C,
-                                       double &D) {
-    if (j == n - 1) {  // Dirichlet row (:200-204)
-        A = 0.0;
-        C = 0.0;
-        B = 1.0;
-        D = UL;
-        return;
-    }
-    const double dx2 = dx * dx;
-    double g = -H1 * Um1 / dt;
-    A = -h2p / dx2 + (-h3p * (1.0 - bp) / dx);
-    if (j == 0) {
-        B = H1 / dt + h2p / dx2 + (-h3p * bp / dx);
-        C = 0.0;
-    } else {
-        B = H1 / dt + (h2m + h2p) / dx2 + (-h3p * bp + h3m * (1.0 - bm)) / dx;
-        C = -h2m / dx2 + h3m * bm / dx;
-    }
-    B += -h6;
+// h2m/h3m/bm: H2, H3, beta at j-1/2 (pass zeros for the first row: its left-boundary formulas
+// :145-146,:165-166 are the interior ones with the j-1/2 terms absent); h2p/h3p/bp at j+1/2.
+// g4 is the H4 term already formed (0 when H4 is absent); h6, h7 are 0 when absent.
+// `last` selects the Dirichlet row (:200-204).  Returns A (super), B (diag), C (sub), D = -g.
+template <bool EXACT>
+__device__ __forceinline__ void fd_row(bool last, double H1, double Um1, const Recip &rc, double UL, double h2m,
+                                       double h3m, double bm, double h2p, double h3p, double bp, double g4,
+                                       double h6, double h7, double &A, double &B, double &C, double &D) {
+    double g = cdiv<EXACT>(-H1 * Um1, rc.dt, rc.idt);
+    double a = cdiv<EXACT>(-h2p, rc.dx2, rc.idx2) + cdiv<EXACT>(-h3p * (1.0 - bp), rc.dx, rc.idx);
+    double b = cdiv<EXACT>(H1, rc.dt, rc.idt) + cdiv<EXACT>(h2m + h2p, rc.dx2, rc.idx2) +
+               cdiv<EXACT>(-h3p * bp + h3m * (1.0 - bm), rc.dx, rc.idx);
+    double c = cdiv<EXACT>(-h2m, rc.dx2, rc.idx2) + cdiv<EXACT>(h3m * bm, rc.dx, rc.idx);
+    b += -h6;
     g += g4;
     g += -h7;
-    D = -g;
+    A = last ? 0.0 : a;
+    B = last ? 1.0 : b;
+    C = last ? 0.0 : c;
+    D = last ? UL : -g;
 }
 
 }  // namespace tg

@@ -49,25 +49,32 @@ struct WaveGroup {
         return pred;
     }
     // Parallel cyclic reduction of the unit-diagonal system s_t y_{t-1} + y_t + p_t y_{t+1} = r_t.
-    __device__ double pcr(double s, double p, double r, int &singular) const {
+    // dl_t = 1 + s_t + p_t (the row's diagonal-dominance slack) is carried along and every new diagonal is
+    // formed as slack - s - p: for the M-matrices of the transport problem (s, p <= 0 <= dl) all those sums
+    // have terms of one sign, so no cancellation eats the small slack as 1 - pm*s - sp*p would.
+    __device__ double pcr(double s, double p, double dl, double r, int &singular) const {
 #pragma unroll
         for (int h = 1; h < LPP; h <<= 1) {
-            double sm = from_left(s, h, 0.0), pm = from_left(p, h, 0.0), rm = from_left(r, h, 0.0);
-            double sp = from_right(s, h, 0.0), pp = from_right(p, h, 0.0), rp = from_right(r, h, 0.0);
-            double g = 1.0 - pm * s - sp * p;
+            const double sm = from_left(s, h, 0.0), rm = from_left(r, h, 0.0);
+            const double dm = from_left(dl, h, 1.0);
+            const double pp = from_right(p, h, 0.0), rp = from_right(r, h, 0.0);
+            const double dp = from_right(dl, h, 1.0);
+            const double d2 = dl - s * dm - p * dp;
+            const double s2 = -(sm * s);
+            const double p2 = -(pp * p);
+            const double g = d2 - s2 - p2;
             singular |= (g == 0.0);
-            double inv = 1.0 / g;
+            const double inv = 1.0 / g;
             r = (r - rm * s - rp * p) * inv;
-            double s2 = -(sm * s) * inv;
-            double p2 = -(pp * p) * inv;
-            s = s2;
-            p = p2;
+            s = s2 * inv;
+            p = p2 * inv;
+            dl = d2 * inv;
         }
         return r;
     }
 };
 
-// One workgroup of T_ threads per profile.  `lds` must hold at least 6*T_ doubles.
+// One workgroup of T_ threads per profile.  `lds` must hold at least 8*T_ doubles.
 template <int T_>
 struct BlockGroup {
     static constexpr int T = T_;
@@ -117,27 +124,30 @@ struct BlockGroup {
     }
     __device__ int any(int pred) const { return __syncthreads_or(pred); }
 
-    __device__ double pcr(double s, double p, double r, int &singular) const {
-        // double-buffered rows in LDS: buffer k holds s,p,r at lds_[k*3*T_ + {0,1,2}*T_ + t]
+    __device__ double pcr(double s, double p, double dl, double r, int &singular) const {
+        // double-buffered rows in LDS: buffer k holds s,p,dl,r at lds_[k*4*T_ + {0,1,2,3}*T_ + t]
         int cur = 0;
 #pragma unroll 1
         for (int h = 1; h < T_; h <<= 1) {
-            double *bs = lds_ + cur * 3 * T_, *bp = bs + T_, *br = bp + T_;
+            double *bs = lds_ + cur * 4 * T_, *bp = bs + T_, *bd = bp + T_, *br = bd + T_;
             bs[t_] = s;
             bp[t_] = p;
+            bd[t_] = dl;
             br[t_] = r;
             __syncthreads();
-            double sm = 0.0, pm = 0.0, rm = 0.0, sp = 0.0, pp = 0.0, rp = 0.0;
-            if (t_ >= h) { sm = bs[t_ - h]; pm = bp[t_ - h]; rm = br[t_ - h]; }
-            if (t_ + h < T_) { sp = bs[t_ + h]; pp = bp[t_ + h]; rp = br[t_ + h]; }
-            double g = 1.0 - pm * s - sp * p;
+            double sm = 0.0, dm = 1.0, rm = 0.0, pp = 0.0, dp = 1.0, rp = 0.0;
+            if (t_ >= h) { sm = bs[t_ - h]; dm = bd[t_ - h]; rm = br[t_ - h]; }
+            if (t_ + h < T_) { pp = bp[t_ + h]; dp = bd[t_ + h]; rp = br[t_ + h]; }
+            const double d2 = dl - s * dm - p * dp;
+            const double s2 = -(sm * s);
+            const double p2 = -(pp * p);
+            const double g = d2 - s2 - p2;
             singular |= (g == 0.0);
-            double inv = 1.0 / g;
+            const double inv = 1.0 / g;
             r = (r - rm * s - rp * p) * inv;
-            double s2 = -(sm * s) * inv;
-            double p2 = -(pp * p) * inv;
-            s = s2;
-            p = p2;
+            s = s2 * inv;
+            p = p2 * inv;
+            dl = d2 * inv;
             cur ^= 1;
         }
         __syncthreads();

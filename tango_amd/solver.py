@@ -1,0 +1,485 @@
+"""Time-step / Picard-iteration driver with the interface of tango/solver.py:32-595.
+
+Two execution paths sit behind the same Solver class:
+
+* generic path -- any user compute_all_H callbacks and any flux model, as in the reference.  Every
+  numerical step (EWMA, flux split, assembly, residual, tridiagonal / pair-coupled solve) is a HIP kernel
+  called through tango_amd's modules; arrays cross the host boundary around each call.  With 1-D profiles
+  the control flow and results are the reference's; with (profiles, N) arrays all profiles advance in
+  lock-step until every one of them has converged.
+
+* fused path -- chosen automatically for the problems whose flux model and source are built into the fused
+  kernels (one-field Shestakov ensembles: extras.shestakov_nonlinear_diffusion.AnalyticFluxModel +
+  ComputeAllH; the three-field nonlinear-nu ensemble of extras.threefield).  The state stays on the device,
+  one kernel launch advances every active profile by one full iteration, and each profile is frozen on the
+  iteration on which the reference would have stopped it (its residual, evaluated before the solve, is below
+  tol; the solve of that iteration still happens, tango/solver.py:150-154, 219-228).
+"""
+from __future__ import division, absolute_import
+
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _hip as H
+from . import fieldgroups, tango_logging
+from . import multifield as _mf
+from . import lodestro_method as _lm
+
+
+def duration_as_hms(seconds):
+    """'h:mm:ss.s' rendering of a duration (tango/utilities/util.py:3-20)."""
+    m, s = divmod(seconds, 60)
+    h, m = divmod(m, 60)
+    return '%d:%02d:%04.1f' % (h, m, s)
+
+
+class Solver(object):
+    def __init__(self, L, x, tArray, maxIterations, tol, compute_all_H_all_fields, fields,
+                 startIterationNumber=0, profiles=None, maxIterationsPerSet=np.inf,
+                 useTreadLightly=False, treadLightlyParams=None,
+                 useTreadInitially=False, treadInitiallyParams=None,
+                 useInnerIteration=False, innerIterationMaxCount=20,
+                 user_control_func=None,
+                 saveFluxesInMemory=False,
+                 iterationsPerCheck=1, saveProfileHistory=None):
+        """Arguments up to saveFluxesInMemory are those of tango/solver.py:33-39.
+
+        iterationsPerCheck  (fused path) iterations launched between two host reads of the convergence
+                            counters; results do not depend on it, converged profiles are skipped on the device.
+        saveProfileHistory  keep profilesAllIterations (profiles x maxIterations x N values); default: only
+                            for single-profile runs.
+        """
+        self.L = L
+        self.x = x
+        self.N = len(x)
+        self.dx = x[1] - x[0]
+        self.tArray = tArray
+        self.maxIterations = maxIterations
+        self.tol = tol
+        self.compute_all_H_all_fields = compute_all_H_all_fields
+        self.fields = fields
+        self.useTreadLightly = useTreadLightly
+        self.treadLightlyParams = treadLightlyParams if treadLightlyParams is not None else {}
+        self.useTreadInitially = useTreadInitially
+        self.treadInitiallyParams = treadInitiallyParams if treadInitiallyParams is not None else {}
+        self.useInnerIteration = useInnerIteration
+        self.innerIterationMaxCount = innerIterationMaxCount
+        self.saveFluxesInMemory = saveFluxesInMemory
+        if user_control_func is not None:
+            assert callable(user_control_func), "user_control_func must be callable (e.g., a function)"
+        self.user_control_func = user_control_func
+
+        if profiles is None:
+            self.profiles = {field.label: field.profile_mminus1 for field in fields}
+        else:
+            self.profiles = profiles
+        self.fileHandlerExecutor = _NoHandlers()
+
+        self.solutionError = False
+        self.t = 0
+        self.dt = None
+        self.countStoredIterations = 0
+        self.iterationNumber = startIterationNumber
+        self.maxIterationsPerSet = maxIterationsPerSet
+        self.converged = None
+        self.errHistory = np.zeros(self.maxIterations)
+        self.errHistoryFinal = None
+        self.tFinal = tArray[-1]
+        self.m = 0
+        self.reachedEnd = False
+        self.profilesAllIterations = None
+        self.fluxesAllIterations = None
+        self.normalizedResids = None
+        self.datadict = None
+        self.iterationsPerProfile = None
+
+        first = np.asarray(self.profiles[fields[0].label])
+        self.batched = first.ndim == 2
+        self.numProfiles = first.shape[0] if self.batched else 1
+        self.saveProfileHistory = (not self.batched) if saveProfileHistory is None else saveProfileHistory
+        self.iterationsPerCheck = max(1, int(iterationsPerCheck))
+
+        self.profilesAllTimesteps = {}
+        self.fluxesAllTimesteps = {}
+        for field in self.fields:
+            shape = (len(tArray),) + np.shape(self.profiles[field.label])
+            self.profilesAllTimesteps[field.label] = np.zeros(shape)
+            self.fluxesAllTimesteps[field.label] = np.zeros(shape)
+            self.profilesAllTimesteps[field.label][self.m] = self.profiles[field.label]
+
+        self.is_unacceptable_one_profile = is_unacceptable_one_profile
+        self._fused = _plan_fused(self)
+
+    # ------------------------------------------------------------------ time step
+    def take_timestep(self):
+        """One implicit time step: iterate until converged, out of iterations, or invalid."""
+        self.m += 1
+        self.converged = False
+        (self.t, self.dt) = self._get_tdt(self.tArray, self.m)
+        self.errHistory[:] = 0
+        self._alloc_history()
+        tango_logging.info("Timestep m={}:  Beginning iteration loop ...".format(self.m))
+
+        if self._fused is not None:
+            self._fused.run_timestep(self)
+        else:
+            while (self.iterationNumber < self.maxIterations
+                   and self.countStoredIterations < self.maxIterationsPerSet
+                   and not self.converged
+                   and not self.solutionError):
+                self.compute_next_iteration()
+
+        if self.converged:
+            tango_logging.info("Timestep m={}:  Converged!  Successfully found the solution for t={}.  Rms error={}.  "
+                               "Took {} iterations.".format(self.m, self.t, self._last_err(), self.iterationNumber))
+            if self.m >= len(self.tArray) - 1:
+                tango_logging.info("Reached the final timestep m={} at t={}.  Simulation ending...".format(self.m, self.t))
+                self.reachedEnd = True
+
+        k = self.countStoredIterations
+        self.errHistoryFinal = self.errHistory[..., 0:k]
+        for field in self.fields:
+            if self.profilesAllIterations is not None:
+                self.profilesAllIterations[field.label] = self.profilesAllIterations[field.label][0:k]
+                self.fluxesAllIterations[field.label] = self.fluxesAllIterations[field.label][0:k]
+            self.profilesAllTimesteps[field.label][self.m] = self.profiles[field.label]
+            if self.profilesAllIterations is not None and k > 0:
+                self.fluxesAllTimesteps[field.label][self.m] = self.fluxesAllIterations[field.label][-1]
+                if self.m == 1:
+                    self.fluxesAllTimesteps[field.label][0] = self.fluxesAllIterations[field.label][0]
+        for field in self.fields:
+            field.profile_mminus1 = self.profiles[field.label]
+        self.iterationNumber = 0
+        self.countStoredIterations = 0
+
+    def _alloc_history(self):
+        if not self.saveProfileHistory:
+            self.profilesAllIterations = None
+            self.fluxesAllIterations = None
+            return
+        shape = (self.maxIterations,) + np.shape(self.profiles[self.fields[0].label])
+        self.profilesAllIterations = {f.label: np.zeros(shape) for f in self.fields}
+        self.fluxesAllIterations = {f.label: np.zeros(shape) for f in self.fields}
+
+    def _last_err(self):
+        i = self.iterationNumber - 1
+        return self.errHistory[..., i] if i >= 0 else None
+
+    # ------------------------------------------------------------------ generic path
+    def _assemble(self, HCoeffsAllFields, dtau):
+        groups = fieldgroups.fields_to_fieldgroups(self.fields, HCoeffsAllFields)
+        for g in groups:
+            g.matrixEqn = g.Hcoeffs_to_matrix_eqn(dtau, self.dx, g.rightBC, g.psi_mminus1, g.HCoeffs)
+        return groups
+
+    @staticmethod
+    def _solve(groups):
+        for g in groups:
+            g.profileSolution = g.solve_matrix_eqn(g.matrixEqn)
+        return fieldgroups.fieldgroups_to_profiles(groups)
+
+    def compute_next_iteration(self):
+        """One Picard iteration of the generic path (tango/solver.py:188-272)."""
+        startTime = time.time()
+        if self.user_control_func is not None:
+            self.user_control_func(self)
+        index = self.countStoredIterations
+
+        if self.useTreadLightly or self.useTreadInitially:
+            for field in self.fields:     # the "previous timestep" slot holds the previous iterate
+                field.profile_mminus1 = self.profiles[field.label]
+
+        (HCoeffsAllFields, HCoeffsTurbAllFields, extradataAllFields) = \
+            self.compute_all_H_all_fields(self.t, self.x, self.profiles)
+
+        dtau = self.dt
+        if self.useTreadInitially and self.iterationNumber < self.treadInitiallyParams['numInitialSteps']:
+            dtau = self.treadInitiallyParams['dtau']
+
+        groups = self._assemble(HCoeffsAllFields, dtau)
+        (self.converged, rmsError, normalizedResids) = self.check_convergence(groups, self.profiles, self.tol)
+        self.errHistory[index] = np.max(rmsError)
+        self.normalizedResids = normalizedResids
+        self.profiles = self._solve(groups)
+
+        if self.useTreadLightly:
+            self.tread_lightly(HCoeffsTurbAllFields)
+        if self.useInnerIteration:
+            (HCoeffsAllFields, _, _) = self.perform_inner_iteration(HCoeffsTurbAllFields)
+
+        tango_logging.debug("...iteration {} took a wall time of {}".format(
+            self.iterationNumber, duration_as_hms(time.time() - startTime)))
+
+        self.datadict = self._pkgdata(HCoeffsAllFields=HCoeffsAllFields, extradataAllFields=extradataAllFields,
+                                      profiles=self.profiles, normalizedResids=normalizedResids,
+                                      rmsError=rmsError, iterationNumber=self.iterationNumber)
+        if self.profilesAllIterations is not None:
+            for field in self.fields:
+                self.profilesAllIterations[field.label][index] = self.profiles[field.label]
+                if self.saveFluxesInMemory and extradataAllFields is not None:
+                    self.fluxesAllIterations[field.label][index] = extradataAllFields[field.label]['fluxTurbGrid']
+        self.fileHandlerExecutor.execute_scheduled(self.datadict, self.iterationNumber)
+        self.check_profiles_are_valid(self.profiles)
+
+        self.countStoredIterations += 1
+        self.iterationNumber += 1
+        if self.iterationNumber >= self.maxIterations:
+            tango_logging.info("Timestep m={} and time t={}:  maxIterations ({}) reached.  Error={} while tol={}".format(
+                self.m, self.t, self.maxIterations, rmsError, self.tol))
+        if self.countStoredIterations >= self.maxIterationsPerSet:
+            tango_logging.info("Timestep m={} and time t={}:  maxIterationsPerSet ({}) reached.  Error={} while tol={}.  "
+                               "Shutting down...".format(self.m, self.t, self.maxIterationsPerSet, rmsError, self.tol))
+
+    def perform_inner_iteration(self, HCoeffsTurbAllFields):
+        """A fixed number of iterations with the turbulent coefficients frozen (tango/solver.py:274-309)."""
+        count = 0
+        while True:
+            (HCoeffsAllFields, _, _) = self.compute_all_H_all_fields(
+                self.t, self.x, self.profiles, computeTurbulence=False, HCoeffsTurbAllFields=HCoeffsTurbAllFields)
+            groups = self._assemble(HCoeffsAllFields, self.dt)
+            (_, rmsError, normalizedResids) = self.check_convergence(groups, self.profiles, self.tol)
+            self.profiles = self._solve(groups)
+            count += 1
+            if count >= self.innerIterationMaxCount:
+                break
+        return (HCoeffsAllFields, normalizedResids, rmsError)
+
+    def tread_lightly(self, HCoeffsTurbAllFields):
+        """Halve the pseudo-timestep, restarting from the previous iterate with the turbulent coefficients
+        frozen, until no profile changes too much in one iteration (tango/solver.py:311-372)."""
+        previous = {field.label: field.profile_mminus1 for field in self.fields}
+        if not self.is_unacceptable(previous, self.profiles):
+            return
+
+        def trial(dtau):
+            (HCoeffsAllFields, _, _) = self.compute_all_H_all_fields(
+                self.t, self.x, previous, computeTurbulence=False, HCoeffsTurbAllFields=HCoeffsTurbAllFields)
+            return self._solve(self._assemble(HCoeffsAllFields, dtau))
+
+        dtau = self.dt
+        while True:
+            dtau /= 2
+            trialProfiles = trial(dtau)
+            if not self.is_unacceptable(previous, trialProfiles):
+                break
+        tango_logging.info(f'used tread lightly on iteration {self.iterationNumber}.  dtau={dtau}')
+        self.profiles = trialProfiles
+
+    def is_unacceptable(self, oldProfiles, newProfiles):
+        maxFractionalChange = self.treadLightlyParams.get('maxFractionalChange', 0.2)
+        innerFraction = self.treadLightlyParams.get('innerFraction', 0.5)
+        for field in self.fields:
+            if self.is_unacceptable_one_profile(oldProfiles[field.label], newProfiles[field.label],
+                                                maxFractionalChange=maxFractionalChange, innerFraction=innerFraction):
+                return True
+        return False
+
+    @property
+    def ok(self):
+        """True until a stop condition is met (tango/solver.py:404-418)."""
+        if self.solutionError:
+            return False
+        if self.m >= len(self.tArray) - 1 or self.t >= self.tFinal:
+            return False
+        if self.iterationNumber >= self.maxIterations:
+            return False
+        if self.countStoredIterations >= self.maxIterationsPerSet:
+            return False
+        return True
+
+    def check_profiles_are_valid(self, profiles):
+        """NaN, Inf or negative values stop the solve gracefully (tango/solver.py:420-439)."""
+        for label in profiles:
+            profile = np.asarray(profiles[label])
+            if not np.all(np.isfinite(profile)):
+                tango_logging.error("field {}: NaN or Inf detected in profile at l={}.  Aborting...".format(label, self.iterationNumber))
+                self.solutionError = True
+                break
+            if np.any(profile < 0):
+                tango_logging.error("field {}: Negative value detected in profile at l={}.  Aborting...".format(label, self.iterationNumber))
+                self.solutionError = True
+                break
+
+    def check_convergence(self, fieldGroups, profiles, tol):
+        """rms over all fields of the normalised residuals (tango/solver.py:441-475); one value per profile
+        for ensembles, converged when every profile is below tol."""
+        normalizedResids = {}
+        for g in fieldGroups:
+            normalizedResids.update(g.calculate_residual(g.matrixEqn, profiles))
+        totalLength = 0
+        sumOfSquaresResid = 0
+        for label in normalizedResids:
+            resid = normalizedResids[label]
+            totalLength += np.shape(resid)[-1]
+            sumOfSquaresResid = sumOfSquaresResid + np.sum(resid ** 2, axis=-1)
+        rmsError = np.sqrt(1 / totalLength * sumOfSquaresResid)
+        converged = bool(np.all(rmsError < tol))
+        return (converged, rmsError, normalizedResids)
+
+    @staticmethod
+    def _get_tdt(tArray, timestepNumber):
+        tNew = tArray[timestepNumber]
+        return tNew, tNew - tArray[timestepNumber - 1]
+
+    def _pkgdata(self, HCoeffsAllFields=None, extradataAllFields=None, profiles=None, normalizedResids=None,
+                 rmsError=None, iterationNumber=None):
+        """Per-iteration data in the layout the reference hands to its file handlers (tango/solver.py:497-532)."""
+        data = {'errHistory': rmsError, 'iterationNumber': iterationNumber}
+        for label in HCoeffsAllFields:
+            entry = {'profile': profiles[label], 'normalizedResid': normalizedResids[label]}
+            if extradataAllFields is not None:
+                entry = self._merge_two_dicts(entry, extradataAllFields[label])
+            data[label] = entry
+            self._pkgdata_HCoeffs_helper(data, HCoeffsAllFields, label)
+        return data
+
+    def _pkgdata_HCoeffs_helper(self, data, HCoeffsAllFields, label):
+        for name in ('H1', 'H2', 'H3', 'H4', 'H6', 'H7', 'H8'):
+            Hj = getattr(HCoeffsAllFields[label], name)
+            data[label][name] = Hj if Hj is not None else np.zeros_like(HCoeffsAllFields[label].H1)
+
+    @staticmethod
+    def _merge_two_dicts(x, y):
+        z = dict(x)
+        z.update(y)
+        return z
+
+
+class _NoHandlers(object):
+    """Stand-in for the reference's file-handler executor (tango/handlers.py:15-83): HDF5 output is outside this
+    package; the per-iteration data is available as Solver.datadict."""
+
+    def execute_scheduled(self, datadict, iterationNumber):
+        pass
+
+    def add_handler(self, handler):
+        raise NotImplementedError('file handlers are not part of tango_amd; read Solver.datadict instead')
+
+
+def is_unacceptable_one_profile(oldProfile, newProfile, maxFractionalChange=0.2, innerFraction=0.5):
+    """True if any point of the inner part of the profile changed by at least maxFractionalChange
+    (tango/solver.py:564-595)."""
+    oldProfile, newProfile = np.asarray(oldProfile), np.asarray(newProfile)
+    k = int(innerFraction * oldProfile.shape[-1])
+    change = (newProfile[..., :k] - oldProfile[..., :k]) / oldProfile[..., :k]
+    return bool(np.any(np.abs(change) >= maxFractionalChange))
+
+
+# ---------------------------------------------------------------------- fused path
+def _plan_fused(s):
+    """Return a fused-path runner when the problem is one the fused kernels implement, else None."""
+    if (s.user_control_func is not None or s.useTreadLightly or s.useTreadInitially or s.useInnerIteration
+            or s.saveFluxesInMemory or s.maxIterationsPerSet != np.inf):
+        return None
+    call = s.compute_all_H_all_fields
+    if not isinstance(call, _mf.ComputeAllHAllFields) or type(call.turbhandler) is not _lm.TurbulenceHandler:
+        return None
+    th = call.turbhandler
+    if th.doSmoothing or th.isNonCartesian or call.fields is not s.fields and list(call.fields) != list(s.fields):
+        return None
+    for f in s.fields:
+        m = f.lodestroMethod
+        if type(f.gridMapper) is not _mf.GridsNull or type(m) is not _lm.lm:
+            return None
+        sp = m._fluxSplitter
+        if sp.ftheta != sp._default_ftheta or np.ndim(sp.gxxAvg) or np.ndim(sp.gradxAvg) or sp.gxxAvg != 1 or sp.gradxAvg != 1:
+            return None
+    model = getattr(th.fluxModel, 'fused_flux_model', None)
+    if model == 'shestakov' and len(s.fields) == 1 and s.fields[0].coupledTo is None \
+            and getattr(s.fields[0].compute_all_H, 'fused_source', None) is not None \
+            and th.dxTurbGrid == s.dx and th.fluxModel.dx == s.dx:
+        return _Fused1F(s)
+    if model == 'threefield_nonlinear_nu' and len(s.fields) == 3:
+        from .extras import threefield
+        return threefield.plan(s)
+    return None
+
+
+class _Fused1F(object):
+    """Device-resident one-field ensemble stepped by tg_picard_1f_step."""
+
+    def __init__(self, s):
+        f = s.fields[0]
+        self.label = f.label
+        u0 = np.atleast_2d(np.asarray(s.profiles[f.label], dtype=np.float64))
+        self.nb, self.n = u0.shape
+        nb = self.nb
+        self.u = H.DeviceArray.from_host(u0)
+        self.um1 = H.DeviceArray.from_host(np.atleast_2d(np.asarray(f.profile_mminus1, dtype=np.float64)))
+        self.uE, self.DE, self.cE = (H.DeviceArray((nb, self.n), zero=True) for _ in range(3))
+        self.status = H.DeviceArray((nb,), np.int32, zero=True)
+        self.iters = H.DeviceArray((nb,), np.int32, zero=True)
+        self.err = H.DeviceArray((nb, s.maxIterations), zero=True)
+        self.counts = H.DeviceArray((4,), np.int64, zero=True)
+        bc = np.broadcast_to(np.asarray(f.rightBC, dtype=np.float64), (nb,))
+        _, S0, delta = f.compute_all_H.fused_source
+        self.UL = H.DeviceArray.from_host(bc)
+        self.S0 = H.DeviceArray.from_host(np.broadcast_to(np.asarray(S0, dtype=np.float64), (nb,)))
+        self.delta = H.DeviceArray.from_host(np.broadcast_to(np.asarray(delta, dtype=np.float64), (nb,)))
+        self.xd = H.DeviceArray.from_host(np.asarray(s.x, dtype=np.float64))
+        m = f.lodestroMethod
+        if m._EWMAProfile._yEWMA_lminus1 is not None:    # restart: EWMA memories supplied by the caller
+            self.uE.set(np.atleast_2d(m._EWMAProfile._yEWMA_lminus1))
+            self.DE.set(np.atleast_2d(m._EWMATurbD._yEWMA_lminus1))
+            self.cE.set(np.atleast_2d(m._EWMATurbc._yEWMA_lminus1))
+            self.status.set(np.full((nb,), H.ST_SEEDED, np.int32))
+        self.state = H.State1F(nb, self.n, self.u.ptr, self.um1.ptr, self.uE.ptr, self.DE.ptr, self.cE.ptr,
+                               self.status.ptr, self.iters.ptr, self.err.ptr, s.maxIterations)
+
+    def params(self, s):
+        m = s.fields[0].lodestroMethod
+        a_turb, a_prof = m.get_ewma_params()
+        tp = m._fluxSplitter.thetaParams
+        q = H.Params1F()
+        q.dt, q.dx, q.a_turb, q.a_prof = float(s.dt), float(s.dx), float(a_turb), float(a_prof)
+        q.Dmin, q.Dmax, q.dpdx_thr, q.tol = float(tp['Dmin']), float(tp['Dmax']), float(tp['dpdxThreshold']), float(s.tol)
+        q.UL, q.S0, q.delta, q.x = self.UL.ptr, self.S0.ptr, self.delta.ptr, self.xd.ptr
+        q.flux_model, q.smooth_window, q.fixed_count, q.frozen_turb = H.FLUX_SHESTAKOV, 1, 0, 0
+        return q
+
+    def run_timestep(self, s):
+        q = self.params(s)
+        if s.m > 1:      # new timestep: previous solution becomes u_{m-1}; keep the EWMA memories
+            self.um1.copy_from(self.u)
+            st = self.status.to_host() & H.ST_SEEDED
+            self.status.set(st.astype(np.int32))
+            H.check(H.lib.tg_memset(self.iters.ptr, 0, self.iters.nbytes, H.stream()))
+            H.check(H.lib.tg_memset(self.err.ptr, 0, self.err.nbytes, H.stream()))
+        done = s.iterationNumber
+        hist = s.profilesAllIterations
+        while done < s.maxIterations:
+            k = 1 if hist is not None else min(s.iterationsPerCheck, s.maxIterations - done)
+            for _ in range(k):
+                H.check(H.lib.tg_picard_1f_step(C.byref(self.state), C.byref(q), H.stream()))
+            done += k
+            if hist is not None:
+                snap = self.u.to_host()
+                hist[self.label][done - 1] = snap if s.batched else snap[0]
+            H.check(H.lib.tg_status_reduce(self.status.ptr, self.nb, self.counts.ptr, H.stream()))
+            active, conv, invalid, _ = (int(v) for v in self.counts.to_host())
+            if active == 0:
+                break
+        self.finish(s)
+
+    def finish(self, s):
+        status = self.status.to_host()
+        iters = self.iters.to_host()
+        err = self.err.to_host()
+        u = self.u.to_host()
+        s.iterationsPerProfile = iters.astype(np.int64)
+        s.iterationNumber = int(iters.max())
+        s.countStoredIterations = s.iterationNumber
+        s.converged = bool(np.all(status & H.ST_CONVERGED))
+        s.solutionError = bool(np.any(status & H.ST_INVALID))
+        s.profileStatus = status
+        if s.batched:
+            s.errHistory = err
+            s.profiles = {self.label: u}
+        else:
+            s.errHistory = err[0].copy()
+            s.profiles = {self.label: u[0]}
+        m = s.fields[0].lodestroMethod
+        pick = (lambda a: a) if s.batched else (lambda a: a[0])
+        m.set_ewma_iterates(pick(self.uE.to_host()), pick(self.DE.to_host()), pick(self.cE.to_host()))

@@ -1,0 +1,194 @@
+"""HIP kernels (called through tango_amd's reference-named API, i.e. through the C ABI) against the golden
+vectors produced by the reference and against the CPU oracle.  Parity bar: 1e-10 relative for fp64 results
+(stated per test; most are at the 1e-14 level)."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+from oracle import tango_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope='module')
+def tango():
+    import tango_amd
+    assert tango_amd.device_count() > 0, 'GPU tests need a GPU'
+    return tango_amd
+
+
+def test_tridiag_golden(tango, golden):
+    g = golden('g1_tridiag')
+    for tag in ('t12', 'r8', 'r500', 'r8192'):
+        A, B, C, D = (g[f'{tag}_{k}'] for k in 'ABCD')
+        assert relerr(tango.tridiag.solve(A, B, C, D), g[f'{tag}_u']) < 1e-13
+        assert relerr(tango.tridiag.solve_with_scipy(A, B, C, D), g[f'{tag}_u']) < 1e-13
+        assert relerr(tango.tridiag.solve_python(A, B, C, D), g[f'{tag}_u_py']) < 1e-13
+    # the reference's own test (tests/test_tridiag.py:7-25)
+    A, B, C, D = (g[f't12_{k}'] for k in 'ABCD')
+    M = np.diag(B) + np.diag(A[:-1], 1) + np.diag(C[1:], -1)
+    assert np.linalg.norm(tango.tridiag.solve(A, B, C, D) - np.linalg.solve(M, D)) < 1e-14
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 7, 8, 9, 63, 64, 65, 255, 256, 500, 511, 512, 513, 1024, 1500, 4096, 8192, 10000, 16384])
+def test_tridiag_sizes_batched(tango, n):
+    rng = np.random.default_rng(n)
+    nb = 5 if n < 4096 else 2
+    A = rng.uniform(-1, 1, (nb, n)); C = rng.uniform(-1, 1, (nb, n))
+    B = (np.abs(A) + np.abs(C) + rng.uniform(0.05, 1, (nb, n))) * rng.choice([-1.0, 1.0], (nb, 1))
+    D = rng.normal(size=(nb, n))
+    A[:, -1] = 7.0; C[:, 0] = -3.0          # must be ignored, as LAPACK's band storage ignores them
+    ref = orc.tridiag_solve(A, B, C, D)
+    assert relerr(tango.tridiag.solve(A, B, C, D), ref) < 1e-12
+    # one profile given as a 1-D array returns a 1-D array
+    one = tango.tridiag.solve(A[0], B[0], C[0], D[0])
+    assert one.shape == (n,) and relerr(one, ref[0]) < 1e-12
+    # batch-fastest (interleaved) layout
+    dev = [tango.DeviceArray.from_host(np.ascontiguousarray(v.T)) for v in (A, B, C, D)]
+    from tango_amd import _ops, _hip
+    u = _ops.tridiag_solve(*dev, layout=_hip.BATCH_FASTEST).to_host().T
+    assert relerr(u, ref) < 1e-12
+
+
+def test_tridiag_inputs_untouched_and_errors(tango):
+    A = np.array([0.1, 0.1, 0.0]); B = np.array([1.0, 1.0, 1.0]); C = np.array([0.0, 0.1, 0.1]); D = np.array([1.0, 2.0, 3.0])
+    keep = [v.copy() for v in (A, B, C, D)]
+    tango.tridiag.solve(A, B, C, D)
+    assert all(np.array_equal(a, b) for a, b in zip(keep, (A, B, C, D)))
+    with pytest.raises(AssertionError):
+        tango.tridiag.solve(A, B[:2], C, D)
+    with pytest.raises(AssertionError):
+        tango.tridiag.solve_python(np.array([0.1, 0.1, 0.5]), B, C, D)
+    with pytest.raises(np.linalg.LinAlgError):
+        tango.tridiag.solve(np.zeros(3), np.zeros(3), np.zeros(3), np.ones(3))
+
+
+def test_tridiag_picard_matrices_vs_extended_precision(tango):
+    """On the ill-conditioned Picard matrices (cond ~1e8 at N=512, ~1e11 at N=8192) the GPU solve must be at
+    least as close to an extended-precision solution as LAPACK's pivoted solve is."""
+    def thomas_ld(A, B, C, D):
+        A, B, C, D = (np.asarray(v, dtype=np.longdouble) for v in (A, B, C, D))
+        n = len(B); cp = np.empty(n, np.longdouble); dp = np.empty(n, np.longdouble)
+        cp[0] = A[0] / B[0]; dp[0] = D[0] / B[0]
+        for j in range(1, n):
+            den = B[j] - C[j] * cp[j - 1]; cp[j] = A[j] / den; dp[j] = (D[j] - C[j] * dp[j - 1]) / den
+        u = np.empty(n, np.longdouble); u[-1] = dp[-1]
+        for j in range(n - 2, -1, -1):
+            u[j] = dp[j] - cp[j] * u[j + 1]
+        return u.astype(float)
+    for N, bar in ((512, 1e-11), (8192, 5e-10)):
+        dx = 1.0 / (N - 1); x = np.arange(N) * dx
+        st = orc.State1F(1 - 0.5 * x)
+        for _ in range(6):
+            H2, H3, _ = orc.turb_coeffs_1f(st, dx, 0.3, 0.3)
+            A, B, C, f = orc.h_to_matrix(1e4, dx, 1e-2, st.um1, np.ones(N), H2=H2, H3=H3, H7=orc.shestakov_source(x))
+            ref = orc.tridiag_solve(A, B, C, f)
+            st.u = ref
+        exact = thomas_ld(A, B, C, f)
+        got = tango.tridiag.solve(A, B, C, f)
+        assert relerr(got, ref) < bar
+        assert relerr(got, exact) <= max(2 * relerr(ref, exact), 1e-13)
+
+
+@pytest.mark.parametrize('tag,keys', [('cart', ('H2', 'H7')), ('polar', ('H2', 'H7')), ('conv', ('H2', 'H3', 'H7')),
+                                      ('h4', ('H2', 'H4', 'H7')), ('rnd', ('H2', 'H3', 'H4', 'H6', 'H7'))])
+def test_h_to_matrix_golden(tango, golden, tag, keys):
+    g = golden('g2_assembly')
+    kw = {k: g[f'{tag}_{k}'] for k in keys}
+    out = tango.HToMatrixFD.H_to_matrix(float(g[f'{tag}_dt']), float(g[f'{tag}_dx']), float(g[f'{tag}_UL']),
+                                        g[f'{tag}_U'], g[f'{tag}_H1'], **kw)
+    for got, k in zip(out, 'ABCD'):
+        assert got.shape == g[f'{tag}_{k}'].shape
+        assert relerr(got, g[f'{tag}_{k}']) < 1e-14, k
+    if f'{tag}_u' in g:
+        u = tango.HToMatrixFD.H_to_matrix_and_solve(float(g[f'{tag}_dt']), float(g[f'{tag}_dx']), float(g[f'{tag}_UL']),
+                                                    g[f'{tag}_U'], g[f'{tag}_H1'], **kw)
+        assert relerr(u, g[f'{tag}_u']) < TOL
+
+
+def test_h_to_matrix_h3_only_and_batched(tango, golden):
+    g = golden('g2_assembly')
+    dt, dx, UL = float(g['rnd_dt']), float(g['rnd_dx']), float(g['rnd_UL'])
+    out = tango.HToMatrixFD.H_to_matrix(dt, dx, UL, g['rnd_U'], g['rnd_H1'], H3=g['rnd_H3'], H7=g['rnd_H7'])
+    for got, k in zip(out, 'ABCD'):
+        assert relerr(got, g[f'h3only_{k}']) < 1e-14
+    # ensemble: per-profile U, H2, UL, dt; shared H1, H3, H7
+    U = np.stack([g['rnd_U'], g['rnd_U'][::-1], g['rnd_U'] * 2])
+    H2 = np.stack([g['rnd_H2'], g['rnd_H2'] * 2, g['rnd_H2'] * 0.5])
+    ULs = np.array([1.7, 0.3, 9.0]); dts = np.array([0.37, 5.0, 1e4])
+    ref = orc.h_to_matrix(dts, dx, ULs, U, g['rnd_H1'], H2=H2, H3=g['rnd_H3'], H7=g['rnd_H7'])
+    got = tango.HToMatrixFD.H_to_matrix(dts, dx, ULs, U, g['rnd_H1'], H2=H2, H3=g['rnd_H3'], H7=g['rnd_H7'])
+    for a, b in zip(got, ref):
+        assert a.shape == (3, 257) and relerr(a, b) < 1e-14
+    with pytest.raises(AssertionError):
+        tango.HToMatrixFD.H_to_matrix(dt, dx, UL, g['rnd_U'], g['rnd_H1'][:-1])
+
+
+def test_flux_split_golden(tango, golden):
+    g = golden('g4_fluxsplit')
+    th = {'Dmin': float(g['shest_Dmin']), 'Dmax': float(g['shest_Dmax']), 'dpdxThreshold': float(g['shest_thr'])}
+    fs = tango.lodestro_method.FluxSplit(th)
+    for tag in ('it0', 'it20'):
+        flux = tango.extras.shestakov_nonlinear_diffusion.get_flux(g[f'{tag}_p'], float(g['shest_dx']))
+        assert relerr(flux, g[f'{tag}_flux']) < 1e-14
+        D, c, data = fs.flux_to_transport_coeffs(g[f'{tag}_flux'], g[f'{tag}_p'], float(g['shest_dx']))
+        assert relerr(D, g[f'{tag}_D']) < 1e-14 and relerr(data['DHat'], g[f'{tag}_DHat']) < 1e-14
+        assert relerr(data['cHat'], g[f'{tag}_cHat']) < 1e-14
+        assert np.array_equal(data['theta'], g[f'{tag}_theta'])       # theta must round exactly as the reference's
+        assert relerr(c, g[f'{tag}_c']) < 1e-13
+    th2 = {'Dmin': float(g['syn_Dmin']), 'Dmax': float(g['syn_Dmax']), 'dpdxThreshold': float(g['syn_thr'])}
+    for tag, kw in (('syn', {}), ('geo', dict(gxxAvg=g['geo_gxx'], gradxAvg=g['geo_gradx']))):
+        D, c, data = tango.lodestro_method.FluxSplit(th2, **kw).flux_to_transport_coeffs(g['syn_flux'], g['syn_p'], float(g['syn_dx']))
+        for got, k in ((D, 'D'), (c, 'c'), (data['DHat'], 'DHat'), (data['cHat'], 'cHat'), (data['theta'], 'theta')):
+            exp = g[f'{tag}_{k}']
+            assert np.array_equal(np.isnan(got), np.isnan(exp)), k
+            m = ~np.isnan(exp)
+            assert relerr(got[m], exp[m]) < 1e-13, (tag, k)
+    # custom theta callable (tango/lodestro_method.py:557-561)
+    th3 = dict(th2, custom_ftheta=lambda DHat, dpdx, p: np.full_like(DHat, 0.25))
+    D, c, data = tango.lodestro_method.FluxSplit(th3).flux_to_transport_coeffs(g['syn_flux'], g['syn_p'], float(g['syn_dx']))
+    m = ~np.isnan(g['syn_DHat'])
+    assert relerr(D[m], 0.25 * g['syn_DHat'][m]) < 1e-14 and relerr(c[m], 0.75 * g['syn_cHat'][m]) < 1e-14
+
+
+def test_small_known_answers(tango, golden):
+    g = golden('g567_small')
+    e = tango.lodestro_method.EWMA(float(g['ewma_param']))
+    for y, exp in zip(g['ewma_in'], g['ewma_out']):
+        assert abs(e.next_ewma_iterate(float(y)) - exp) < 1e-15
+    assert abs(tango.lodestro_method.EWMA._compute_next_ewma(37, 7.1, 0.12) - 10.688) < 1e-13
+    # array EWMA through the kernel, including the seeding call
+    rng = np.random.default_rng(5)
+    ys = rng.normal(size=(4, 3, 33))
+    ea = tango.lodestro_method.EWMA(0.12); prev = None
+    for y in ys:
+        prev = orc.ewma_next(y, prev, 0.12)
+        assert relerr(ea.next_ewma_iterate(y), prev) < 1e-15
+    for w in (1, 3, 4, 5, 11):
+        assert relerr(tango.smoother.Smoother(w).smooth(g['sm_x']), g[f'sm_w{w}']) < 1e-14
+    assert np.allclose(tango.smoother.moving_average(g['sm9_x'], 5), [1., 4., 5.2, 5.6, 5.4, 5., 5.2, 13. / 3, 5], rtol=1e-14)
+    with pytest.raises(AssertionError):
+        tango.smoother.moving_average(g['sm_x'], 4)
+    assert np.allclose(tango.derivatives.dx_centered_difference_edge_first_order(g['d_u'], 0.4), g['d_edge1'], rtol=0, atol=1e-13)
+    assert np.allclose(tango.derivatives.dx_centered_difference(g['d_u'], 0.4), g['d_edge2'], rtol=0, atol=1e-13)
+
+
+def test_residual_golden(tango, golden):
+    g = golden('g11_residual')
+    ufg = tango.fieldgroups.UncoupledFieldGroup('n')
+    r = ufg.calculate_residual(tango.fieldgroups.UncoupledMatrixEqn(g['A'], g['B'], g['C'], g['f']), {'n': g['u']})['n']
+    assert relerr(r, g['r']) < 1e-14
+    from tango_amd import _ops
+    _, ss = _ops.residual(g['A'], g['B'], g['C'], g['f'], g['u'])
+    assert abs(np.sqrt(ss / 300) - float(g['rms'])) < 1e-14 * float(g['rms']) * 10
+
+
+def test_uncoupled_fieldgroup_chain(tango):
+    """tests/test_fieldgroups.py:28-66 of the reference: assemble + solve reproduce analytic steady states."""
+    N = 500; dx = 1 / (N - 0.5); x = np.linspace(dx / 2, 1, N)
+    ufg = tango.fieldgroups.UncoupledFieldGroup('default')
+    H = tango.multifield.HCoefficients(H1=x, H2=1.3 * x, H7=x ** 2)
+    meq = ufg.Hcoeffs_to_matrix_eqn(1e9, dx, 0.03, 0.3 * np.sin(np.pi * x) + 0.03 * x, H)
+    sol = ufg.solve_matrix_eqn(meq)['default']
+    assert np.allclose(sol, 0.03 + 1 / (9 * 1.3) * (1 - x ** 3), rtol=1e-4)

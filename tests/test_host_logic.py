@@ -1,0 +1,138 @@
+"""Host-side logic that needs no GPU: data-model validation, grouping, ensemble generators, sharding.
+The expectations follow the reference's own tests (tests/test_multifield.py, tests/test_fieldgroups.py)."""
+import numpy as np
+import pytest
+
+import tango_amd as tango
+from tango_amd import multifield, fieldgroups
+from tango_amd.ensemble import shard_range, shestakov_ensemble
+from oracle import tango_oracle as orc
+
+
+def _fields():
+    p = np.ones(6)
+    f0 = multifield.Field(label='a', rightBC=1.0, profile_mminus1=p, compute_all_H=lambda *a: None)
+    f1 = multifield.Field(label='b', rightBC=2.0, profile_mminus1=p, compute_all_H=lambda *a: None, coupledTo='c')
+    f2 = multifield.Field(label='c', rightBC=3.0, profile_mminus1=p, compute_all_H=lambda *a: None, coupledTo='b')
+    return [f0, f1, f2]
+
+
+def test_field_requires_label():
+    with pytest.raises(ValueError):
+        multifield.Field()
+
+
+def test_check_fields_initialize():
+    multifield.check_fields_initialize(_fields())
+    fs = _fields(); fs[1].label = 'a'
+    with pytest.raises(ValueError):
+        multifield.check_fields_initialize(fs)
+    fs = _fields(); fs[0].rightBC = np.ones(3)
+    with pytest.raises(ValueError):
+        multifield.check_fields_initialize(fs)
+    fs = _fields(); fs[2].profile_mminus1 = np.ones(7)
+    with pytest.raises(ValueError):
+        multifield.check_fields_initialize(fs)
+    fs = _fields(); fs[2].coupledTo = 'a'
+    with pytest.raises(ValueError):
+        multifield.check_fields_initialize(fs)
+    fs = _fields(); fs[1].coupledTo = 'b'
+    with pytest.raises(ValueError):
+        multifield.check_fields_initialize(fs)
+    fs = _fields(); fs[0].compute_all_H = 3
+    with pytest.raises(ValueError):
+        multifield.check_fields_initialize(fs)
+    # ensembles: one boundary value per profile is accepted
+    f = multifield.Field(label='n', rightBC=np.ones(4), profile_mminus1=np.ones((4, 6)), compute_all_H=lambda *a: None)
+    multifield.check_fields_initialize([f])
+
+
+def test_get_field_by_label():
+    fs = _fields()
+    assert multifield.get_field_by_label(fs, 'c') is fs[2]
+    with pytest.raises(ValueError):
+        multifield.get_field_by_label(fs, 'zz')
+
+
+def test_hcoefficients_add():
+    a = multifield.HCoefficients(H1=np.ones(3), H2=np.full(3, 2.0))
+    b = multifield.HCoefficients(H2=np.full(3, 5.0), H7=np.full(3, 7.0))
+    c = a + b
+    assert np.array_equal(c.H1, np.ones(3)) and np.array_equal(c.H2, np.full(3, 7.0)) and np.array_equal(c.H7, np.full(3, 7.0))
+    assert c.H3 is None and c.H8 is None
+    assert 'H2=' in repr(c) and 'H3' not in repr(c)
+
+
+def test_fields_to_fieldgroups_order_and_contents():
+    fs = _fields()
+    Hs = {f.label: multifield.HCoefficients(H1=np.ones(6), H8=np.full(6, float(i))) for i, f in enumerate(fs)}
+    groups = fieldgroups.fields_to_fieldgroups(fs, Hs)
+    assert len(groups) == 2
+    assert isinstance(groups[0], fieldgroups.UncoupledFieldGroup) and groups[0].label == 'a'
+    assert groups[0].HCoeffs is Hs['a'] and groups[0].rightBC == 1.0
+    g = groups[1]
+    assert (g.label0, g.label1) == ('b', 'c') and g.rightBC == (2.0, 3.0)
+    assert np.array_equal(g.HCoeffs.J8, Hs['b'].H8) and np.array_equal(g.HCoeffs.K8, Hs['c'].H8)
+    # pair listed partner-first
+    groups = fieldgroups.fields_to_fieldgroups([fs[2], fs[0], fs[1]], Hs)
+    assert (groups[0].label0, groups[0].label1) == ('c', 'b') and groups[1].label == 'a'
+
+
+def test_fieldgroups_to_profiles():
+    g0 = fieldgroups.UncoupledFieldGroup('f0'); g0.profileSolution = {'f0': np.ones(4)}
+    g1 = fieldgroups.PairCoupledFieldGroup('f1', 'f2'); g1.profileSolution = {'f1': 2 * np.ones(4), 'f2': 3 * np.ones(4)}
+    p = fieldgroups.fieldgroups_to_profiles([g0, g1])
+    assert sorted(p) == ['f0', 'f1', 'f2'] and p['f2'][0] == 3
+
+
+def test_is_unacceptable_one_profile():
+    from tango_amd.solver import is_unacceptable_one_profile as bad
+    old = np.linspace(1, 2, 10)
+    assert not bad(old, old * 1.1)
+    assert bad(old, old * 1.2)                      # >= 20 % counts
+    new = old.copy(); new[7] *= 3                   # outside the inner half: ignored
+    assert not bad(old, new)
+    new = old.copy(); new[2] *= 0.5
+    assert bad(old, new)
+
+
+def test_smoother_window_rule():
+    assert tango.smoother.add_one_if_even(4) == 5 and tango.smoother.add_one_if_even(5) == 5
+    with pytest.raises(ValueError):
+        tango.smoother.add_one_if_even(2.5)
+    x = np.arange(5.0)
+    assert tango.smoother.moving_average(x, 1) is x
+
+
+def test_shard_range_covers_everything():
+    for nb in (1, 7, 64, 65536, 1048576):
+        for world in (1, 2, 3, 8):
+            ranges = [shard_range(nb, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == nb
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in ranges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_ensemble_generator_matches_oracle_and_shards():
+    full = shestakov_ensemble(64, 128)
+    ref = orc.shestakov_ensemble(64, 128)
+    for k in ('u0', 'nL', 'S0', 'delta', 'x'):
+        assert np.array_equal(full[k], ref[k])
+    lo, hi = shard_range(64, 1, 3)
+    part = shestakov_ensemble(64, 128, lo=lo, hi=hi)
+    assert np.array_equal(part['u0'], full['u0'][lo:hi]) and np.array_equal(part['nL'], full['nL'][lo:hi])
+    assert full['nL'][0] == 1e-2 and np.array_equal(full['u0'][0], 1 - 0.5 * full['x'])
+
+
+def test_solver_constructor_and_ok_without_gpu():
+    """Constructing a Solver touches no kernel on the generic path; `ok` follows tango/solver.py:404-418."""
+    x = np.linspace(0, 1, 16)
+    f = multifield.Field(label='n', rightBC=0.1, profile_mminus1=np.ones(16), compute_all_H=lambda *a: None)
+    s = tango.solver.Solver(1, x, np.array([0, 1.0]), 10, 1e-9, lambda *a, **k: None, [f])
+    assert s.ok and s.N == 16 and s._fused is None
+    s.solutionError = True
+    assert not s.ok
+    s.solutionError = False; s.iterationNumber = 10
+    assert not s.ok
+    assert tango.solver.Solver._get_tdt(np.array([0, 2.5, 10]), 2) == (10, 7.5)
