@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Benchmark of the fused Picard iteration on the synthetic Shestakov ensemble.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one Picard iteration (EWMA -> flux -> split -> EWMA -> assembly -> residual -> tridiagonal
+solve -> validity check) of every profile of the ensemble, all profiles forced active.  Each GPU (one
+process per GPU; for N > 1 launch through torch.distributed.run) holds 65 536 profiles x 512 grid points,
+fp64, resident in HBM before the timed region; the batch shards with no data exchange, the only collective is
+the all-reduce of the convergence counters (RCCL), issued every --check-every steps inside the timed region.
+
+Rank 0 prints ONE JSON line.  `value` is in units of "Picard iterations per second of a 65 536-profile
+ensemble": (profiles on all GPUs / 65 536) x steps / time, so that at N = 1 it is literally the iteration rate
+of the 64K-profile ensemble the metric names and at N GPUs the aggregate of N such shards (weak scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E nominal peak
+BYTES_PER_POINT = 72           # 5 arrays read + 4 written per point per iteration, fp64
+PROFILES_PER_GPU = 65536
+N_GRID = 512
+
+
+def cpu_baseline(n, seconds=12.0):
+    """The CPU restatement of the same iteration (oracle/tango_oracle.c, OpenMP over profiles) on a 4096-profile
+    subsample of the same ensemble, timed on this host.  Checker code used as a reported baseline only."""
+    from oracle import c_oracle
+    from tango_amd.ensemble import shestakov_ensemble
+    sub = 4096
+    ens = shestakov_ensemble(PROFILES_PER_GPU, n, lo=0, hi=sub)
+    threads = min(16, os.cpu_count() or 1)
+    E = c_oracle.Ensemble1F(ens, fixed_count=True, max_iter=1)
+    used = E.step(threads)                       # warm-up, also reports the thread count
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        E.step(threads)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or steps >= 400:
+            break
+    rate = steps * sub / PROFILES_PER_GPU / el
+    return {'value': rate, 'unit': 'iters/s (65536-profile ensemble equivalents)', 'cores': int(used), 'kind': 'port',
+            'sample': f'{steps} iterations of the first {sub} of the 65536 profiles, N={n}, {el:.1f} s wall, '
+                      f'C restatement of the reference path (oracle/tango_oracle.c), OpenMP {used} threads',
+            'profile_iterations_per_s': steps * sub / el}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--check-every', type=int, default=8, help='steps between convergence-counter all-reduces')
+    ap.add_argument('--profiles-per-gpu', type=int, default=PROFILES_PER_GPU)
+    ap.add_argument('--n', type=int, default=N_GRID)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import tango_amd
+    from tango_amd import _hip as H
+    from tango_amd import distributed as D
+    from tango_amd.ensemble import OneFieldEnsemble, shard_range, shestakov_ensemble
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f'warning: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    stream = torch.cuda.current_stream()
+    H.set_stream(stream.cuda_stream)
+
+    nb_total = args.profiles_per_gpu * world
+    lo, hi = shard_range(nb_total, rank, world)
+    ens = shestakov_ensemble(nb_total, args.n, lo=lo, hi=hi)
+    alloc = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=dev)     # torch owns the state pool
+    E = OneFieldEnsemble(ens, a_turb=0.3, a_prof=1.0, tol=1e-11, fixed_count=True, keep_err=False, alloc=alloc)
+    counts = torch.zeros(4, dtype=torch.int64, device=dev)      # all-reduced over ranks by RCCL
+
+    def step(i):
+        E.step(stream.cuda_stream)
+        if (i + 1) % args.check_every == 0:
+            E.reduce_status(stream.cuda_stream, counts.data_ptr())
+            D.allreduce_counts(counts)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for i in range(args.steps):
+        step(i)
+    e1.record(stream)
+    fence()
+    wall = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+
+    t = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall, ev_ms = float(t[0]), float(t[1])
+    bad = int(np.count_nonzero(E.status.to_host() & 6))
+
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        value = (nb_total / PROFILES_PER_GPU) * args.steps / wall
+        bytes_per_launch = (hi - lo) * args.n * BYTES_PER_POINT
+        kernel_ms = ev_ms / args.steps          # launches are back to back on one stream: events bracket K kernels
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f'picard_1f_{args.profiles_per_gpu}x{args.n}')
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'Picard iters/sec, 64K-profile Shestakov ensemble N=512 fp64; % of HBM peak',
+            'value': value,
+            'unit': 'iters/s (65536-profile ensemble equivalents)',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'one-field Shestakov ensemble, {args.profiles_per_gpu} profiles x N={args.n} per GPU, '
+                                   f'EWMA 0.3/1.0, dt=1e4, fused assemble+solve, all profiles active, seed 12345',
+                       'profiles_total': nb_total, 'grid_points': args.n, 'check_every': args.check_every,
+                       'parallelism': f'batch sharded over {world} GPU(s), RCCL all-reduce of 4 int64 counters'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'picard_1f_kernel', 'kernel_ms': kernel_ms,
+                         'algorithmic_bytes_per_launch': bytes_per_launch},
+            'invalid_profiles': bad,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.n, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

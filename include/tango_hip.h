@@ -155,10 +155,10 @@ typedef struct {
     const double *UL;    /* (nb,) right boundary values */
     const double *dt_b;  /* optional (nb,) per-profile pseudo-timestep */
     const double *H1;    /* optional (n,) shared; NULL = 1 */
-    const double *H7;    /* optional source array, stride h7_stride; NULL = S0*[x<delta] */
+    const double *H7;    /* optional source array, stride h7_stride; NULL = box source below */
     int64_t h7_stride;
-    const double *S0, *delta; /* (nb,) source parameters used when H7 == NULL */
-    const double *x;          /* optional (n,) grid; NULL = j*dx */
+    const double *S0;        /* (nb,) box source used when H7 == NULL: H7_j = S0[b] for j < src_cut[b], else 0 */
+    const int32_t *src_cut;  /* (nb,) number of grid points with x < delta (the grid is increasing) */
     const double *Vprime, *gxx, *gradx;    /* optional (n,) geometry on the transport grid */
     const double *gxx_turb, *gradx_turb;   /* optional (n,) geometry used by the flux split */
     const double *flux;  /* (nb,n) flux when flux_model == TG_FLUX_EXTERNAL (profile EWMA already advanced) */

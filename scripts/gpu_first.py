@@ -33,12 +33,12 @@ def run_fused(nb, n, iters, a_prof, fixed=True, tol=1e-11):
     uE = H.DeviceArray((nb, n), zero=True); DE = H.DeviceArray((nb, n), zero=True); cE = H.DeviceArray((nb, n), zero=True)
     status = H.DeviceArray((nb,), np.int32, zero=True); its = H.DeviceArray((nb,), np.int32, zero=True)
     err = H.DeviceArray((nb, iters), zero=True)
-    UL = H.DeviceArray.from_host(ens['nL']); S0 = H.DeviceArray.from_host(ens['S0']); dl = H.DeviceArray.from_host(ens['delta'])
+    UL = H.DeviceArray.from_host(ens['nL']); S0 = H.DeviceArray.from_host(ens['S0']); dl = H.DeviceArray.from_host(np.searchsorted(ens['x'], ens['delta']).astype(np.int32))
     S = H.State1F(nb, n, u.ptr, um1.ptr, uE.ptr, DE.ptr, cE.ptr, status.ptr, its.ptr, err.ptr, iters)
     Q = H.Params1F()
     Q.dt, Q.dx, Q.a_turb, Q.a_prof = 1e4, ens['dx'], 0.3, a_prof
     Q.Dmin, Q.Dmax, Q.dpdx_thr, Q.tol = 1e-5, 1e13, 10.0, tol
-    Q.UL, Q.S0, Q.delta = UL.ptr, S0.ptr, dl.ptr
+    Q.UL, Q.S0, Q.src_cut = UL.ptr, S0.ptr, dl.ptr
     Q.flux_model, Q.smooth_window, Q.fixed_count, Q.frozen_turb = 0, 1, int(fixed), 0
     keep = (u, um1, uE, DE, cE, status, its, err, UL, S0, dl)
     t0 = time.time()

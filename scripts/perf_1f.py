@@ -32,12 +32,12 @@ def main(nb=65536, n=512, iters=30, warm=5, a_prof=1.0):
     pms = p0.elapsed_time(p1) / 10
     print(f'stream probe 5r+4w (skew {skew} B): {pms:.4f} ms  {nb * n * 72 / pms / 1e9:.3f} TB/s', flush=True)
     status = torch.zeros(nb, dtype=torch.int32, device=dev); its = torch.zeros(nb, dtype=torch.int32, device=dev)
-    UL, S0, dl = t(ens['nL']), t(ens['S0']), t(ens['delta'])
+    UL, S0, dl = t(ens['nL']), t(ens['S0']), t(np.searchsorted(ens['x'], ens['delta']).astype(np.int32), torch.int32)
     S = H.State1F(nb, n, u.data_ptr(), um1.data_ptr(), uE.data_ptr(), DE.data_ptr(), cE.data_ptr(), status.data_ptr(), its.data_ptr(), None, 0)
     Q = H.Params1F()
     Q.dt, Q.dx, Q.a_turb, Q.a_prof = 1e4, ens['dx'], 0.3, a_prof
     Q.Dmin, Q.Dmax, Q.dpdx_thr, Q.tol = 1e-5, 1e13, 10.0, 1e-11
-    Q.UL, Q.S0, Q.delta = UL.data_ptr(), S0.data_ptr(), dl.data_ptr()
+    Q.UL, Q.S0, Q.src_cut = UL.data_ptr(), S0.data_ptr(), dl.data_ptr()
     Q.flux_model, Q.smooth_window, Q.fixed_count, Q.frozen_turb = 0, 1, 1, 0
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(warm):

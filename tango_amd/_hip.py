@@ -49,7 +49,7 @@ class State1F(C.Structure):
 class Params1F(C.Structure):
     _fields_ = [('dt', _dbl), ('dx', _dbl), ('a_turb', _dbl), ('a_prof', _dbl), ('Dmin', _dbl), ('Dmax', _dbl),
                 ('dpdx_thr', _dbl), ('tol', _dbl), ('UL', _p), ('dt_b', _p), ('H1', _p), ('H7', _p),
-                ('h7_stride', _i64), ('S0', _p), ('delta', _p), ('x', _p), ('Vprime', _p), ('gxx', _p),
+                ('h7_stride', _i64), ('S0', _p), ('src_cut', _p), ('Vprime', _p), ('gxx', _p),
                 ('gradx', _p), ('gxx_turb', _p), ('gradx_turb', _p), ('flux', _p), ('flux_model', C.c_int32),
                 ('smooth_window', C.c_int32), ('fixed_count', C.c_int32), ('frozen_turb', C.c_int32)]
 
@@ -194,6 +194,8 @@ def ptr_of(a):
     if a is None:
         return None
     if isinstance(a, DeviceArray):
+        return a.ptr
+    if hasattr(a, 'ptr') and hasattr(a, 'owner'):      # ensemble.DeviceView
         return a.ptr
     if hasattr(a, 'data_ptr'):
         if hasattr(a, 'is_cuda') and not a.is_cuda:

@@ -453,7 +453,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     u[P + 1] = g.from_right(u[1], 1, 0.0);
 
     const double S0 = Q.H7 ? 0.0 : Q.S0[b];
-    const double delta = Q.H7 ? 0.0 : Q.delta[b];
+    const int src_cut = Q.H7 ? 0 : Q.src_cut[b];
 
     // Assemble row by row and eliminate at once.  Half-grid slot "m" lies between local points
     // i-1 and i, slot "p" between i and i+1; the p values of row i are the m values of row i+1.
@@ -472,12 +472,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         const double hp3 = (h3[i + 1] + h3[i + 2]) / 2.0;
         const double bp = fbeta_point(hp2, hp3, rc.dx);
         const double H1 = Q.H1 ? Q.H1[jc] : 1.0;
-        double h7;
-        if (Q.H7) h7 = Q.H7[b * Q.h7_stride + jc];
-        else {
-            const double x = Q.x ? Q.x[jc] : (double)j * rc.dx;
-            h7 = (x < delta) ? S0 : 0.0;
-        }
+        const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + jc] : ((j < src_cut) ? S0 : 0.0);
         double A, B, C, f;
         fd_row<EXACT>(last, H1, um1[i], rc, UL, hm2, hm3, bm, hp2, hp3, bp, 0.0, 0.0, h7, A, B, C, f);
         if (!FULL) {
@@ -735,7 +730,7 @@ int tg_picard_1f_step(const tg_state_1f *st, const tg_params_1f *q, tg_stream st
     if (int e = check_dims(st->nb, st->n, 3)) return e;
     if (!st->u || !st->um1 || !st->uE || !st->DE || !st->cE || !st->status || !st->iters) return fail(TG_ERR_ARG, "NULL state array%s");
     if (!q->UL) return fail(TG_ERR_ARG, "UL is required%s");
-    if (!q->H7 && (!q->S0 || !q->delta)) return fail(TG_ERR_ARG, "either H7 or (S0, delta) is required%s");
+    if (!q->H7 && (!q->S0 || !q->src_cut)) return fail(TG_ERR_ARG, "either H7 or (S0, src_cut) is required%s");
     if (q->flux_model == TG_FLUX_EXTERNAL && !q->flux) return fail(TG_ERR_ARG, "external flux model needs a flux array%s");
     if (q->flux_model != TG_FLUX_EXTERNAL && q->flux_model != TG_FLUX_SHESTAKOV) return fail(TG_ERR_ARG, "unknown flux model%s");
     if (q->smooth_window > 1) return fail(TG_ERR_UNSUPPORTED, "flux smoothing is not fused; smooth the flux with tg_moving_average and pass it as an external flux%s");

@@ -416,9 +416,10 @@ class _Fused1F(object):
         bc = np.broadcast_to(np.asarray(f.rightBC, dtype=np.float64), (nb,))
         _, S0, delta = f.compute_all_H.fused_source
         self.UL = H.DeviceArray.from_host(bc)
+        from .ensemble import source_cut
         self.S0 = H.DeviceArray.from_host(np.broadcast_to(np.asarray(S0, dtype=np.float64), (nb,)))
-        self.delta = H.DeviceArray.from_host(np.broadcast_to(np.asarray(delta, dtype=np.float64), (nb,)))
-        self.xd = H.DeviceArray.from_host(np.asarray(s.x, dtype=np.float64))
+        cut = np.broadcast_to(source_cut(s.x, delta), (nb,))
+        self.src_cut = H.DeviceArray.from_host(np.ascontiguousarray(cut, dtype=np.int32))
         m = f.lodestroMethod
         if m._EWMAProfile._yEWMA_lminus1 is not None:    # restart: EWMA memories supplied by the caller
             self.uE.set(np.atleast_2d(m._EWMAProfile._yEWMA_lminus1))
@@ -435,7 +436,7 @@ class _Fused1F(object):
         q = H.Params1F()
         q.dt, q.dx, q.a_turb, q.a_prof = float(s.dt), float(s.dx), float(a_turb), float(a_prof)
         q.Dmin, q.Dmax, q.dpdx_thr, q.tol = float(tp['Dmin']), float(tp['Dmax']), float(tp['dpdxThreshold']), float(s.tol)
-        q.UL, q.S0, q.delta, q.x = self.UL.ptr, self.S0.ptr, self.delta.ptr, self.xd.ptr
+        q.UL, q.S0, q.src_cut = self.UL.ptr, self.S0.ptr, self.src_cut.ptr
         q.flux_model, q.smooth_window, q.fixed_count, q.frozen_turb = H.FLUX_SHESTAKOV, 1, 0, 0
         return q
 
