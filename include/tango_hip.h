@@ -129,7 +129,7 @@ int tg_block3_solve(const double *Cb, const double *Bb, const double *Ab, const 
                     int64_t nb, int64_t n, int32_t *status, tg_stream stream);
 
 /* ---- fused Picard iteration, one field --------------------------------------------------------
- * One call = one pass of tango/solver.py:188-272 (compute_next_iteration) for every active profile of
+ * One call = one pass (or, with iters_per_launch = k, up to k passes) of tango/solver.py:188-272 (compute_next_iteration) for every active profile of
  * the ensemble with the analytic flux built in: EWMA(profile) -> flux -> [smoothing] -> FluxSplit ->
  * EWMA(D), EWMA(c) -> H2,H3 -> H_to_matrix -> residual of the current profile -> tridiagonal solve ->
  * validity check.  State arrays are (nb, n) point-fastest and stay resident on the device. */
@@ -166,6 +166,9 @@ typedef struct {
     int32_t smooth_window; /* odd; 1 = no smoothing */
     int32_t fixed_count;   /* nonzero: step every profile regardless of its status, never mark converged */
     int32_t frozen_turb;   /* nonzero: reuse DE,cE as they are (inner iteration, tango/solver.py:274-309) */
+    int32_t iters_per_launch; /* <= 1: one iteration per call; k > 1: up to k iterations per call with the profile
+                                 held in registers in between (each profile still stops on its own iteration) */
+    int32_t reserved_;
 } tg_params_1f;
 
 int tg_picard_1f_step(const tg_state_1f *state, const tg_params_1f *params, tg_stream stream);

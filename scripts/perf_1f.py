@@ -9,7 +9,7 @@ from tango_amd import _hip as H
 from oracle import tango_oracle as orc
 C = H.C
 
-def main(nb=65536, n=512, iters=30, warm=5, a_prof=1.0):
+def main(nb=65536, n=512, iters=30, warm=5, a_prof=1.0, kper=1):
     dev = torch.device('cuda:0')
     H.set_stream(torch.cuda.current_stream().cuda_stream)
     ens = orc.shestakov_ensemble(nb, n)
@@ -39,6 +39,7 @@ def main(nb=65536, n=512, iters=30, warm=5, a_prof=1.0):
     Q.Dmin, Q.Dmax, Q.dpdx_thr, Q.tol = 1e-5, 1e13, 10.0, 1e-11
     Q.UL, Q.S0, Q.src_cut = UL.data_ptr(), S0.data_ptr(), dl.data_ptr()
     Q.flux_model, Q.smooth_window, Q.fixed_count, Q.frozen_turb = 0, 1, 1, 0
+    Q.iters_per_launch = kper
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(warm):
         H.check(H.lib.tg_picard_1f_step(C.byref(S), C.byref(Q), st))
@@ -48,8 +49,8 @@ def main(nb=65536, n=512, iters=30, warm=5, a_prof=1.0):
     for _ in range(iters):
         H.check(H.lib.tg_picard_1f_step(C.byref(S), C.byref(Q), st))
     e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    print(f'nb={nb} n={n}: {ms:.4f} ms/iter  {1e3 / ms:.1f} it/s  {nb * n * 72 / ms / 1e9:.3f} TB/s algorithmic ({nb * n * 72 / ms / 1e9 / 8 * 100:.1f}% of 8 TB/s); invalid={(status & 2).ne(0).sum().item()}', flush=True)
+    ms = e0.elapsed_time(e1) / iters / kper
+    print(f'nb={nb} n={n} k={kper}: {ms:.4f} ms/iter  {1e3 / ms:.1f} it/s  {nb * n * 72 / ms / 1e9:.3f} TB/s algorithmic ({nb * n * 72 / ms / 1e9 / 8 * 100:.1f}% of 8 TB/s); invalid={(status & 2).ne(0).sum().item()}', flush=True)
     # copy bandwidth probe for reference
     a = torch.empty(nb * n * 4, dtype=torch.float64, device=dev); b2 = torch.empty_like(a)
     for _ in range(3): b2.copy_(a)
@@ -60,4 +61,7 @@ def main(nb=65536, n=512, iters=30, warm=5, a_prof=1.0):
     print(f'copy probe: {2 * a.numel() * 8 / ms / 1e9:.3f} TB/s', flush=True)
 
 if __name__ == '__main__':
-    main(*(int(v) for v in sys.argv[1:3])) if len(sys.argv) > 2 else main()
+    if len(sys.argv) > 2:
+        main(int(sys.argv[1]), int(sys.argv[2]), kper=int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+    else:
+        main()

@@ -51,7 +51,8 @@ class Params1F(C.Structure):
                 ('dpdx_thr', _dbl), ('tol', _dbl), ('UL', _p), ('dt_b', _p), ('H1', _p), ('H7', _p),
                 ('h7_stride', _i64), ('S0', _p), ('src_cut', _p), ('Vprime', _p), ('gxx', _p),
                 ('gradx', _p), ('gxx_turb', _p), ('gradx_turb', _p), ('flux', _p), ('flux_model', C.c_int32),
-                ('smooth_window', C.c_int32), ('fixed_count', C.c_int32), ('frozen_turb', C.c_int32)]
+                ('smooth_window', C.c_int32), ('fixed_count', C.c_int32), ('frozen_turb', C.c_int32),
+                ('iters_per_launch', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class State3F(C.Structure):

@@ -363,19 +363,22 @@ __global__ void status_reduce_kernel(const int32_t *__restrict__ status, int64_t
 // ------------------------------------------------------------------------------------------
 // Fused Picard iteration, one field.
 // ------------------------------------------------------------------------------------------
-#ifndef TG_MINW
-#define TG_MINW 1
-#endif
-template <int P, class G, bool FULL>
-__global__ void __launch_bounds__(G::kBlock ? G::T : 256, G::kBlock ? 1 : TG_MINW)
+// One launch advances every active profile by up to Q.iters_per_launch iterations.  The profile stays in
+// registers between those iterations (u, the three EWMA memories and u_{m-1}: 42 doubles per lane), so the
+// state crosses HBM once per launch instead of once per iteration; the convergence test, the freeze of a
+// converged profile and the residual history are per iteration, exactly as with one iteration per launch.
+// GENERAL = false is the Cartesian case with the built-in flux (no geometry arrays, no external flux): H2 and H3
+// are then the EWMA memories themselves and need no registers of their own.
+// MULTI = false compiles the single-iteration form (no loop, no selects on `done`).
+template <int P, class G, bool FULL, bool GENERAL, bool MULTI>
+__global__ void __launch_bounds__(G::kBlock ? G::T : 256, G::kBlock ? 1 : 2)   // two wavefronts per SIMD: <= 256 registers
 picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     extern __shared__ double lds[];
     G g(lds);
     const int64_t b = (int64_t)blockIdx.x * G::profiles_per_block(blockDim.x) + g.profile_in_block();
     if (b >= S_.nb) return;
-    const int st = S_.status[b];
+    int st = S_.status[b];
     if (!Q.fixed_count && (st & (TG_ST_CONVERGED | TG_ST_INVALID))) return;
-    const bool seeded = (st & TG_ST_SEEDED) != 0;
     const int n = (int)S_.n;
     const int t = g.t();
     const int j0 = t * P;
@@ -385,133 +388,178 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     const bool lane_first = (t == 0);
     // grids beyond one wavefront (n > 512) have condition numbers above 1e9: keep the reference's divisions
     constexpr bool EXACT = G::kBlock;
+    const bool external = GENERAL && (Q.flux_model == TG_FLUX_EXTERNAL);
+    const bool geom = GENERAL && (Q.Vprime != nullptr);
+    const int iters = MULTI ? (Q.iters_per_launch > 1 ? Q.iters_per_launch : 1) : 1;
+    const double S0 = Q.H7 ? 0.0 : Q.S0[b];
+    const int src_cut = Q.H7 ? 0 : Q.src_cut[b];
+    const Theta th(Q.Dmin, Q.Dmax, Q.dpdx_thr);
+    const double omp = 1.0 - Q.a_prof, omt = 1.0 - Q.a_turb;
+    int it0 = S_.iters[b];
 
-    // issue every load of the profile up front
-    double u[P + 2], um1[P], DE[P], cE[P];
+    // the whole state of the profile, loaded once
+    double u[P + 2], ue[P], um1[P], DE[P], cE[P];
+    double fl[GENERAL ? P : 1];
     load_chunk<P, FULL>(S_.u + off, n, j0, u + 1, 0.0);
+    load_chunk<P, FULL>(S_.uE + off, n, j0, ue, 1.0);
     load_chunk<P, FULL>(S_.DE + off, n, j0, DE, 0.0);
     load_chunk<P, FULL>(S_.cE + off, n, j0, cE, 0.0);
     load_chunk<P, FULL>(S_.um1 + off, n, j0, um1, 0.0);
-    if (!Q.frozen_turb) {
-        double ue[P + 2];
-        load_chunk<P, FULL>(S_.uE + off, n, j0, ue + 1, 1.0);
-        double fl[P];
-        if (Q.flux_model == TG_FLUX_EXTERNAL) {
-            load_chunk<P, FULL>(Q.flux + off, n, j0, fl, 0.0);
-        } else {
-            // EWMA of the profile (tango/lodestro_method.py:345)
-            const double oma = 1.0 - Q.a_prof;
+    if constexpr (GENERAL) {
+        if (external) load_chunk<P, FULL>(Q.flux + off, n, j0, fl, 0.0);
+    }
+
+    bool done = false;     // this profile needs no further iteration (uniform over its lane group)
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (!MULTI) done = false;
+        // A group that is done keeps executing (other groups of the wavefront may not be) but every update of
+        // its state below is a select on `done`, so nothing of it changes any more.
+        const bool seeded = (st & TG_ST_SEEDED) != 0;
+        if (!Q.frozen_turb) {
+            // EWMA of the profile (tango/lodestro_method.py:345); with an external flux the caller has advanced it
+            if (!external) {
 #pragma unroll
-            for (int i = 0; i < P; ++i) ue[i + 1] = Q.a_prof * u[i + 1] + oma * (seeded ? ue[i + 1] : u[i + 1]);
-            store_chunk<P, FULL>(S_.uE + off, n, j0, ue + 1);
+                for (int i = 0; i < P; ++i) {
+                    const double v = Q.a_prof * u[i + 1] + omp * (seeded ? ue[i] : u[i + 1]);
+                    ue[i] = done ? ue[i] : v;
+                }
+            }
+            const double wl = g.from_left(ue[P - 1], 1, 0.0);
+            const double wr = g.from_right(ue[0], 1, 0.0);
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int j = j0 + i;
+                const int jc = (FULL || j < n) ? j : n - 1;
+                const bool first = (i == 0) && lane_first;
+                const bool last = FULL ? (i == P - 1 && t == G::T - 1) : (j == n - 1);
+                const double pm = (i == 0) ? wl : ue[i > 0 ? i - 1 : 0];
+                const double pp = (i == P - 1) ? wr : ue[i < P - 1 ? i + 1 : 0];
+                const double p = ue[i];
+                const double dpdx = ddx_edge1_point<EXACT>(pm, p, pp, first, last, rc);
+                // flux model (tango/extras/shestakov_nonlinear_diffusion.py:59-60)
+                double flux = -(dpdx * dpdx * dpdx) / (p * p);
+                double gx = 1.0, gr = 1.0;
+                if constexpr (GENERAL) {
+                    flux = external ? fl[i] : flux;
+                    gx = Q.gxx_turb ? Q.gxx_turb[jc] : 1.0;
+                    gr = Q.gradx_turb ? Q.gradx_turb[jc] : 1.0;
+                }
+                double D, c, DH, cH, thv;
+                flux_split_point(flux, p, dpdx, gx, gr, th, D, c, DH, cH, thv);
+                // EWMA of D and c (tango/lodestro_method.py:368-369)
+                const double nD = Q.a_turb * D + omt * (seeded ? DE[i] : D);
+                const double nc = Q.a_turb * c + omt * (seeded ? cE[i] : c);
+                DE[i] = done ? DE[i] : nD;
+                cE[i] = done ? cE[i] : nc;
+            }
         }
-        ue[0] = g.from_left(ue[P], 1, 0.0);
-        ue[P + 1] = g.from_right(ue[1], 1, 0.0);
-        const Theta th(Q.Dmin, Q.Dmax, Q.dpdx_thr);
-        const double omt = 1.0 - Q.a_turb;
+
+        // H2 = V' D <g^xx>, H3 = -V' c <|grad x|> (tango/lodestro_method.py:400-405) at local point k (0..P-1)
+        auto H2at = [&](int k) -> double {
+            if constexpr (GENERAL) {
+                if (geom) {
+                    const int j = j0 + k;
+                    const int jc = (FULL || j < n) ? j : n - 1;
+                    return Q.Vprime[jc] * DE[k] * (Q.gxx ? Q.gxx[jc] : 1.0);
+                }
+            }
+            return DE[k];
+        };
+        auto H3at = [&](int k) -> double {
+            if constexpr (GENERAL) {
+                if (geom) {
+                    const int j = j0 + k;
+                    const int jc = (FULL || j < n) ? j : n - 1;
+                    return -Q.Vprime[jc] * cE[k] * (Q.gradx ? Q.gradx[jc] : 1.0);
+                }
+            }
+            return -cE[k];
+        };
+        const double h2first = H2at(0), h3first = H3at(0), h2last = H2at(P - 1), h3last = H3at(P - 1);
+        const double h2l = g.from_left(h2last, 1, 0.0), h3l = g.from_left(h3last, 1, 0.0);
+        const double h2r = g.from_right(h2first, 1, 0.0), h3r = g.from_right(h3first, 1, 0.0);
+        u[0] = g.from_left(u[P], 1, 0.0);
+        u[P + 1] = g.from_right(u[1], 1, 0.0);
+
+        // Assemble row by row and eliminate at once.  Half-grid slot "m" lies between local points i-1 and i,
+        // slot "p" between i and i+1; the p values of row i are the m values of row i+1.
+        ChunkElim<P> el;
+        double hm2 = lane_first ? 0.0 : (h2l + h2first) / 2.0;
+        double hm3 = lane_first ? 0.0 : (h3l + h3first) / 2.0;
+        double bm = fbeta_point(hm2, hm3, rc.dx);
+        double mx = 0.0, ss = 0.0;
+        double h2c = h2first, h3c = h3first;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const int j = j0 + i;
-            const int jc = (FULL || j < n) ? j : n - 1;
-            const bool first = (i == 0) && lane_first;
+            const bool valid = FULL || (j < n);
             const bool last = FULL ? (i == P - 1 && t == G::T - 1) : (j == n - 1);
-            const double dpdx = ddx_edge1_point<EXACT>(ue[i], ue[i + 1], ue[i + 2], first, last, rc);
-            const double p = ue[i + 1];
-            // flux model (tango/extras/shestakov_nonlinear_diffusion.py:59-60)
-            const double flux = (Q.flux_model == TG_FLUX_EXTERNAL) ? fl[i] : -(dpdx * dpdx * dpdx) / (p * p);
-            double D, c, DH, cH, thv;
-            flux_split_point(flux, p, dpdx, Q.gxx_turb ? Q.gxx_turb[jc] : 1.0, Q.gradx_turb ? Q.gradx_turb[jc] : 1.0, th, D,
-                             c, DH, cH, thv);
-            // EWMA of D and c (tango/lodestro_method.py:368-369)
-            DE[i] = Q.a_turb * D + omt * (seeded ? DE[i] : D);
-            cE[i] = Q.a_turb * c + omt * (seeded ? cE[i] : c);
+            const int jc = valid ? j : n - 1;
+            const double h2n = (i == P - 1) ? h2r : H2at(i < P - 1 ? i + 1 : 0);
+            const double h3n = (i == P - 1) ? h3r : H3at(i < P - 1 ? i + 1 : 0);
+            const double hp2 = (h2c + h2n) / 2.0;
+            const double hp3 = (h3c + h3n) / 2.0;
+            const double bp = fbeta_point(hp2, hp3, rc.dx);
+            const double H1 = Q.H1 ? Q.H1[jc] : 1.0;
+            const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + jc] : ((j < src_cut) ? S0 : 0.0);
+            double A, B, C, f;
+            fd_row<EXACT>(last, H1, um1[i], rc, UL, hm2, hm3, bm, hp2, hp3, bp, 0.0, 0.0, h7, A, B, C, f);
+            if (!FULL) {
+                A = valid ? A : 0.0;
+                B = valid ? B : 1.0;
+                C = valid ? C : 0.0;
+                f = valid ? f : 0.0;
+            }
+            // residual of the current profile with the new matrix (tango/fieldgroups.py:139)
+            const double r = A * u[i + 2] + B * u[i + 1] + C * u[i] - f;
+            ss += valid ? r * r : 0.0;
+            mx = fmax(mx, valid ? fabs(f) : 0.0);
+            el.push(i, C, B, A, f);
+            hm2 = hp2;
+            hm3 = hp3;
+            bm = bp;
+            h2c = h2n;
+            h3c = h3n;
         }
+        // rms of r / max|f| (tango/fieldgroups.py:140, tango/solver.py:464-470)
+        mx = g.max(mx);
+        ss = g.sum(ss);
+        const double rms = sqrt(1.0 / (double)n * (ss / (mx * mx)));
+
+        double x[P];
+        el.finish(g, x);
+        int bad = 0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            bad |= (FULL || j0 + i < n) ? !(isfinite(x[i]) && x[i] >= 0.0) : 0;
+            u[i + 1] = done ? u[i + 1] : x[i];
+        }
+        bad = g.any(bad | (el.singular << 1));
+
+        if (!done) {
+            if (t == 0 && S_.err && it0 < S_.err_stride) S_.err[b * S_.err_stride + it0] = rms;
+            ++it0;
+            if (!Q.frozen_turb) st |= TG_ST_SEEDED;
+            if (!Q.fixed_count && rms < Q.tol) st |= TG_ST_CONVERGED;
+            if (bad & 1) st |= TG_ST_INVALID;
+            if (bad & 2) st |= TG_ST_SINGULAR;
+            done = !Q.fixed_count && (st & (TG_ST_CONVERGED | TG_ST_INVALID));
+        }
+        // leave when every profile handled by this wavefront (workgroup) is done
+        if constexpr (!MULTI) break;
+        if (G::kBlock ? done : !__any(!done)) break;
+    }
+
+    store_chunk<P, FULL>(S_.u + off, n, j0, u + 1);
+    if (!Q.frozen_turb) {
+        if (!external) store_chunk<P, FULL>(S_.uE + off, n, j0, ue);
         store_chunk<P, FULL>(S_.DE + off, n, j0, DE);
         store_chunk<P, FULL>(S_.cE + off, n, j0, cE);
     }
-
-    // H2, H3 on the integer grid with one halo point on each side (tango/lodestro_method.py:400-405)
-    double h2[P + 2], h3[P + 2];
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        if (Q.Vprime) {
-            const int j = j0 + i;
-            const int jc = (FULL || j < n) ? j : n - 1;
-            const double vp = Q.Vprime[jc];
-            h2[i + 1] = vp * DE[i] * (Q.gxx ? Q.gxx[jc] : 1.0);
-            h3[i + 1] = -vp * cE[i] * (Q.gradx ? Q.gradx[jc] : 1.0);
-        } else {
-            h2[i + 1] = DE[i];
-            h3[i + 1] = -cE[i];
-        }
-    }
-    h2[0] = g.from_left(h2[P], 1, 0.0);
-    h3[0] = g.from_left(h3[P], 1, 0.0);
-    h2[P + 1] = g.from_right(h2[1], 1, 0.0);
-    h3[P + 1] = g.from_right(h3[1], 1, 0.0);
-    u[0] = g.from_left(u[P], 1, 0.0);
-    u[P + 1] = g.from_right(u[1], 1, 0.0);
-
-    const double S0 = Q.H7 ? 0.0 : Q.S0[b];
-    const int src_cut = Q.H7 ? 0 : Q.src_cut[b];
-
-    // Assemble row by row and eliminate at once.  Half-grid slot "m" lies between local points
-    // i-1 and i, slot "p" between i and i+1; the p values of row i are the m values of row i+1.
-    ChunkElim<P> el;
-    double hm2 = lane_first ? 0.0 : (h2[0] + h2[1]) / 2.0;
-    double hm3 = lane_first ? 0.0 : (h3[0] + h3[1]) / 2.0;
-    double bm = fbeta_point(hm2, hm3, rc.dx);
-    double mx = 0.0, ss = 0.0;
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const int j = j0 + i;
-        const bool valid = FULL || (j < n);
-        const bool last = FULL ? (i == P - 1 && t == G::T - 1) : (j == n - 1);
-        const int jc = valid ? j : n - 1;
-        const double hp2 = (h2[i + 1] + h2[i + 2]) / 2.0;
-        const double hp3 = (h3[i + 1] + h3[i + 2]) / 2.0;
-        const double bp = fbeta_point(hp2, hp3, rc.dx);
-        const double H1 = Q.H1 ? Q.H1[jc] : 1.0;
-        const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + jc] : ((j < src_cut) ? S0 : 0.0);
-        double A, B, C, f;
-        fd_row<EXACT>(last, H1, um1[i], rc, UL, hm2, hm3, bm, hp2, hp3, bp, 0.0, 0.0, h7, A, B, C, f);
-        if (!FULL) {
-            A = valid ? A : 0.0;
-            B = valid ? B : 1.0;
-            C = valid ? C : 0.0;
-            f = valid ? f : 0.0;
-        }
-        // residual of the current profile with the new matrix (tango/fieldgroups.py:139)
-        const double r = A * u[i + 2] + B * u[i + 1] + C * u[i] - f;
-        ss += valid ? r * r : 0.0;
-        mx = fmax(mx, valid ? fabs(f) : 0.0);
-        el.push(i, C, B, A, f);
-        hm2 = hp2;
-        hm3 = hp3;
-        bm = bp;
-    }
-    // rms of r / max|f| (tango/fieldgroups.py:140, tango/solver.py:464-470)
-    mx = g.max(mx);
-    ss = g.sum(ss);
-    const double rms = sqrt(1.0 / (double)n * (ss / (mx * mx)));
-
-    double x[P];
-    el.finish(g, x);
-    int bad = 0;
-#pragma unroll
-    for (int i = 0; i < P; ++i) bad |= (FULL || j0 + i < n) ? !(isfinite(x[i]) && x[i] >= 0.0) : 0;
-    store_chunk<P, FULL>(S_.u + off, n, j0, x);
-    bad = g.any(bad | (el.singular << 1));
     if (t == 0) {
-        const int it = S_.iters[b];
-        if (S_.err && it < S_.err_stride) S_.err[b * S_.err_stride + it] = rms;
-        S_.iters[b] = it + 1;
-        int ns = st;
-        if (!Q.frozen_turb) ns |= TG_ST_SEEDED;
-        if (!Q.fixed_count && rms < Q.tol) ns |= TG_ST_CONVERGED;
-        if (bad & 1) ns |= TG_ST_INVALID;
-        if (bad & 2) ns |= TG_ST_SINGULAR;
-        S_.status[b] = ns;
+        S_.iters[b] = it0;
+        S_.status[b] = st;
     }
 }
 
@@ -586,8 +634,20 @@ struct Picard1fLauncher {
                        reinterpret_cast<uintptr_t>(st->uE) | reinterpret_cast<uintptr_t>(st->DE) |
                        reinterpret_cast<uintptr_t>(st->cE) | reinterpret_cast<uintptr_t>(q->flux);
         const bool full = (n == P * G::T) && (al & 15) == 0;
-        if (full) hipLaunchKernelGGL((picard_1f_kernel<P, G, true>), dim3(grid), dim3(block), lds, s, *st, *q);
-        else hipLaunchKernelGGL((picard_1f_kernel<P, G, false>), dim3(grid), dim3(block), lds, s, *st, *q);
+        const bool general = q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb;
+        const bool multi = q->iters_per_launch > 1;
+#define TG_LAUNCH_1F(F, GEN, M) hipLaunchKernelGGL((picard_1f_kernel<P, G, F, GEN, M>), dim3(grid), dim3(block), lds, s, *st, *q)
+        if (general) {
+            if (full) TG_LAUNCH_1F(true, true, true);
+            else TG_LAUNCH_1F(false, true, true);
+        } else if (multi) {
+            if (full) TG_LAUNCH_1F(true, false, true);
+            else TG_LAUNCH_1F(false, false, true);
+        } else {
+            if (full) TG_LAUNCH_1F(true, false, false);
+            else TG_LAUNCH_1F(false, false, false);
+        }
+#undef TG_LAUNCH_1F
         return launch_check();
     }
 };
@@ -733,6 +793,7 @@ int tg_picard_1f_step(const tg_state_1f *st, const tg_params_1f *q, tg_stream st
     if (!q->H7 && (!q->S0 || !q->src_cut)) return fail(TG_ERR_ARG, "either H7 or (S0, src_cut) is required%s");
     if (q->flux_model == TG_FLUX_EXTERNAL && !q->flux) return fail(TG_ERR_ARG, "external flux model needs a flux array%s");
     if (q->flux_model != TG_FLUX_EXTERNAL && q->flux_model != TG_FLUX_SHESTAKOV) return fail(TG_ERR_ARG, "unknown flux model%s");
+    if (q->flux_model == TG_FLUX_EXTERNAL && q->iters_per_launch > 1) return fail(TG_ERR_ARG, "an external flux is valid for one iteration only%s");
     if (q->smooth_window > 1) return fail(TG_ERR_UNSUPPORTED, "flux smoothing is not fused; smooth the flux with tg_moving_average and pass it as an external flux%s");
     if (st->err && st->err_stride <= 0) return fail(TG_ERR_ARG, "err_stride must be positive%s");
     if (st->nb == 0) return TG_OK;

@@ -144,8 +144,9 @@ class OneFieldEnsemble:
         self.params = q
         self.max_iter = max_iter
 
-    def step(self, stream=None):
-        """One Picard iteration of every active profile (asynchronous)."""
+    def step(self, stream=None, iters=1):
+        """`iters` Picard iterations of every active profile in one launch (asynchronous)."""
+        self.params.iters_per_launch = int(iters)
         H.check(H.lib.tg_picard_1f_step(C.byref(self.state), C.byref(self.params), stream if stream is not None else H.stream()))
 
     def reduce_status(self, stream=None, counts_ptr=None):

@@ -46,8 +46,10 @@ class Solver(object):
                  iterationsPerCheck=1, saveProfileHistory=None):
         """Arguments up to saveFluxesInMemory are those of tango/solver.py:33-39.
 
-        iterationsPerCheck  (fused path) iterations launched between two host reads of the convergence
-                            counters; results do not depend on it, converged profiles are skipped on the device.
+        iterationsPerCheck  (fused path) iterations per kernel launch and between two host reads of the
+                            convergence counters.  Each profile still stops on its own iteration (the test is made
+                            every iteration on the device); with k > 1 the profiles stay in registers between
+                            iterations, which removes most of the HBM traffic.
         saveProfileHistory  keep profilesAllIterations (profiles x maxIterations x N values); default: only
                             for single-profile runs.
         """
@@ -452,8 +454,8 @@ class _Fused1F(object):
         hist = s.profilesAllIterations
         while done < s.maxIterations:
             k = 1 if hist is not None else min(s.iterationsPerCheck, s.maxIterations - done)
-            for _ in range(k):
-                H.check(H.lib.tg_picard_1f_step(C.byref(self.state), C.byref(q), H.stream()))
+            q.iters_per_launch = k        # k iterations in one launch, the profiles held in registers in between
+            H.check(H.lib.tg_picard_1f_step(C.byref(self.state), C.byref(q), H.stream()))
             done += k
             if hist is not None:
                 snap = self.u.to_host()

@@ -218,3 +218,26 @@ def test_full_size_properties(tango):
     lin = A * np.roll(u[k], -1, axis=1) + B * u[k] + Cc * np.roll(u[k], 1, axis=1) - f
     scale = np.max(np.abs(B) * np.abs(u[k]), axis=1, keepdims=True)
     assert np.max(np.abs(lin) / scale) < 1e-12
+
+
+@pytest.mark.parametrize('N,nb', [(512, 9), (500, 5), (100, 7), (1000, 2)])
+def test_multi_iteration_launch_equals_single_launches(tango, N, nb):
+    """k iterations in one launch (profiles register-resident in between) against k launches of one iteration:
+    same profiles, EWMA memories, residual history, per-profile stop iteration and status."""
+    from tango_amd.ensemble import OneFieldEnsemble
+    ens = orc.shestakov_ensemble(nb, N)
+    for fixed, tol, total in ((True, 1e-11, 12), (False, 3e-3, 36)):   # loose tol: profiles stop on different iterations
+        A = OneFieldEnsemble(ens, a_prof=0.3, tol=tol, max_iter=total, fixed_count=fixed)
+        B = OneFieldEnsemble(ens, a_prof=0.3, tol=tol, max_iter=total, fixed_count=fixed)
+        for _ in range(total):
+            A.step()
+        for k in ((5, 4, 3) if total == 12 else (5, 4, 3, 12, 12)):
+            B.step(iters=k)
+        ia, ib = A.iters.to_host(), B.iters.to_host()
+        assert np.array_equal(ia, ib) and np.array_equal(A.status.to_host(), B.status.to_host())
+        if not fixed:
+            assert len(set(ia.tolist())) > 1 or nb < 3
+            assert np.all(ia < total)
+        for x, y in ((A.u, B.u), (A.uE, B.uE), (A.DE, B.DE), (A.cE, B.cE)):
+            assert relerr(y.to_host(), x.to_host()) < 1e-13
+        assert np.allclose(A.err.to_host(), B.err.to_host(), rtol=1e-9, atol=1e-15)
