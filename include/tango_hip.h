@@ -194,10 +194,15 @@ typedef struct {
 
 typedef struct {
     double dt, dx, a_turb, a_prof, Dmin, Dmax, dpdx_thr, tol;
-    const double *UL[3]; /* (nb,) each */
+    const double *UL[3]; /* (nb,) right boundary values of n, pi, pe */
+    const double *H7[3]; /* (n,) source of each field, shared by all profiles */
     const double *nu0;   /* (nb,) */
-    int32_t fixed_count;
-    int32_t frozen_turb;
+    int32_t fixed_count; /* nonzero: step every profile regardless of its status, never mark converged */
+    int32_t frozen_turb; /* nonzero: one pass of the inner iteration (tango/solver.py:274-309): D, c frozen, no EWMA
+                            advance, no residual history entry, no convergence decision */
+    int32_t outer_count; /* frozen passes only: process the profiles whose iteration count equals this value (those
+                            that took part in the outer iteration just made, converged by it or not) */
+    int32_t reserved_;
 } tg_params_3f;
 
 int tg_picard_3f_step(const tg_state_3f *state, const tg_params_3f *params, tg_stream stream);

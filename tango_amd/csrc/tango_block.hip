@@ -1,10 +1,442 @@
-// Coupled-field entry points (placeholder bodies until the block solvers land).
+// Coupled-field kernels of libtango_hip.so: the pair-coupled (2x2 block) solve, the 3x3 block-tridiagonal
+// solve and the fused three-field Picard iteration.  Same lane-group design as the scalar kernels
+// (tango_hip.hip): a lane owns P = 4 consecutive grid points and keeps its block rows in registers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
 #include "../../include/tango_hip.h"
-extern "C" {
-int tg_pair_solve(const double *, const double *, const double *, const double *, const double *, const double *,
-                  const double *, const double *, const double *, const double *, double *, double *, int64_t, int64_t,
-                  int32_t *, tg_stream) { return TG_ERR_UNSUPPORTED; }
-int tg_block3_solve(const double *, const double *, const double *, const double *, double *, int64_t, int64_t, int32_t *,
-                    tg_stream) { return TG_ERR_UNSUPPORTED; }
-int tg_picard_3f_step(const tg_state_3f *, const tg_params_3f *, tg_stream) { return TG_ERR_UNSUPPORTED; }
+#include "tg_assemble.h"
+#include "tg_block.h"
+#include "tg_comm.h"
+#include "tg_host.h"
+#include "tg_io.h"
+#include "tg_solve.h"
+
+namespace {
+
+using namespace tg;
+
+constexpr int PB = 4;   // grid points per lane in the block kernels
+
+// ------------------------------------------------------------------------------------------
+// C^U U_{j-1} + B^U U_j + A^U U_{j+1} + G^W W_j = D^U  and the same with U <-> W
+// ------------------------------------------------------------------------------------------
+struct PairArgs {
+    const double *AU, *BU, *CU, *DU, *GW, *AW, *BW, *CW, *DW, *GU;
+    double *U, *W;
+};
+
+template <int P, class G>
+__global__ void __launch_bounds__(G::kBlock ? G::T : 256)
+pair_solve_kernel(PairArgs a, int64_t nb, int n, int32_t *__restrict__ status) {
+    extern __shared__ double lds[];
+    G g(lds);
+    const int64_t b = (int64_t)blockIdx.x * G::profiles_per_block(blockDim.x) + g.profile_in_block();
+    if (b >= nb) return;
+    const int j0 = g.t() * P;
+    const int64_t off = b * (int64_t)n;
+    double au[P], bu[P], cu[P], du[P], gw[P], aw[P], bw[P], cw[P], dw[P], gu[P];
+    load_chunk<P, false>(a.AU + off, n, j0, au, 0.0);
+    load_chunk<P, false>(a.BU + off, n, j0, bu, 1.0);
+    load_chunk<P, false>(a.CU + off, n, j0, cu, 0.0);
+    load_chunk<P, false>(a.DU + off, n, j0, du, 0.0);
+    load_chunk<P, false>(a.GW + off, n, j0, gw, 0.0);
+    load_chunk<P, false>(a.AW + off, n, j0, aw, 0.0);
+    load_chunk<P, false>(a.BW + off, n, j0, bw, 1.0);
+    load_chunk<P, false>(a.CW + off, n, j0, cw, 0.0);
+    load_chunk<P, false>(a.DW + off, n, j0, dw, 0.0);
+    load_chunk<P, false>(a.GU + off, n, j0, gu, 0.0);
+    BlockElim<2, P> el;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int j = j0 + i;
+        Mat<2> Cm = mat_zero<2>(), Bm, Am = mat_zero<2>();
+        Vec<2> d;
+        Cm.m[0][0] = (j == 0) ? 0.0 : cu[i];
+        Cm.m[1][1] = (j == 0) ? 0.0 : cw[i];
+        Am.m[0][0] = (j == n - 1) ? 0.0 : au[i];
+        Am.m[1][1] = (j == n - 1) ? 0.0 : aw[i];
+        Bm.m[0][0] = bu[i];
+        Bm.m[0][1] = gw[i];
+        Bm.m[1][0] = gu[i];
+        Bm.m[1][1] = bw[i];
+        d.v[0] = du[i];
+        d.v[1] = dw[i];
+        el.push(i, Cm, Bm, Am, d);
+    }
+    Vec<2> x[P];
+    el.finish(g, x);
+    double xu[P], xw[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        xu[i] = x[i].v[0];
+        xw[i] = x[i].v[1];
+    }
+    store_chunk<P, false>(a.U + off, n, j0, xu);
+    store_chunk<P, false>(a.W + off, n, j0, xw);
+    if (status) {
+        const int sing = g.any(el.singular);
+        if (sing && g.t() == 0) atomicOr(&status[b], TG_ST_SINGULAR);
+    }
 }
+
+// ------------------------------------------------------------------------------------------
+// 3x3 block-tridiagonal solve, blocks stored component-major
+// ------------------------------------------------------------------------------------------
+template <int P, class G>
+__global__ void __launch_bounds__(G::kBlock ? G::T : 256)
+block3_solve_kernel(const double *__restrict__ Cb, const double *__restrict__ Bb, const double *__restrict__ Ab,
+                    const double *__restrict__ d, double *__restrict__ x, int64_t nb, int n, int32_t *__restrict__ status) {
+    extern __shared__ double lds[];
+    G g(lds);
+    const int64_t b = (int64_t)blockIdx.x * G::profiles_per_block(blockDim.x) + g.profile_in_block();
+    if (b >= nb) return;
+    const int j0 = g.t() * P;
+    const int64_t plane = nb * (int64_t)n, off = b * (int64_t)n;
+    BlockElim<3, P> el;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int j = j0 + i;
+        Mat<3> Cm, Bm, Am;
+        Vec<3> dv;
+        const bool valid = j < n;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int64_t k = (r * 3 + c) * plane + off + (valid ? j : 0);
+                Cm.m[r][c] = (valid && j > 0) ? Cb[k] : 0.0;
+                Am.m[r][c] = (valid && j < n - 1) ? Ab[k] : 0.0;
+                Bm.m[r][c] = valid ? Bb[k] : (r == c ? 1.0 : 0.0);
+            }
+            dv.v[r] = valid ? d[r * plane + off + j] : 0.0;
+        }
+        el.push(i, Cm, Bm, Am, dv);
+    }
+    Vec<3> xs[P];
+    el.finish(g, xs);
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+        if (j0 + i < n) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) x[r * plane + off + j0 + i] = xs[i].v[r];
+        }
+    if (status) {
+        const int sing = g.any(el.singular);
+        if (sing && g.t() == 0) atomicOr(&status[b], TG_ST_SINGULAR);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused Picard iteration of the three-field problem n, pi <-> pe
+// (examples/shestakov_threefield_nonlinearnu.py:52-149 on the stack of tango/solver.py:188-272)
+// ------------------------------------------------------------------------------------------
+template <int P, class G>
+__global__ void __launch_bounds__(G::kBlock ? G::T : 256)
+picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
+    extern __shared__ double lds[];
+    G g(lds);
+    const int64_t b = (int64_t)blockIdx.x * G::profiles_per_block(blockDim.x) + g.profile_in_block();
+    if (b >= S_.nb) return;
+    const int st = S_.status[b];
+    const int it = S_.iters[b];
+    if (Q.frozen_turb) {
+        if ((st & TG_ST_INVALID) || (Q.outer_count > 0 && it != Q.outer_count)) return;
+    } else if (!Q.fixed_count && (st & (TG_ST_CONVERGED | TG_ST_INVALID))) {
+        return;
+    }
+    const bool seeded = (st & TG_ST_SEEDED) != 0;
+    const int n = (int)S_.n;
+    const int t = g.t();
+    const int j0 = t * P;
+    const int64_t off = b * S_.n;
+    const Recip rc(Q.dx, Q.dt);
+    const bool lane_first = (t == 0);
+    const Theta th(Q.Dmin, Q.Dmax, Q.dpdx_thr);
+    const double omp = 1.0 - Q.a_prof, omt = 1.0 - Q.a_turb;
+
+    double u[3][P + 2], DE[3][P], cE[3][P];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        load_chunk<P, false>(S_.u[s] + off, n, j0, u[s] + 1, 1.0);
+        load_chunk<P, false>(S_.DE[s] + off, n, j0, DE[s], 0.0);
+        load_chunk<P, false>(S_.cE[s] + off, n, j0, cE[s], 0.0);
+    }
+    if (!Q.frozen_turb) {
+        double ue[3][P + 2];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            load_chunk<P, false>(S_.uE[s] + off, n, j0, ue[s] + 1, 1.0);
+#pragma unroll
+            for (int i = 0; i < P; ++i) ue[s][i + 1] = Q.a_prof * u[s][i + 1] + omp * (seeded ? ue[s][i + 1] : u[s][i + 1]);
+            store_chunk<P, false>(S_.uE[s] + off, n, j0, ue[s] + 1);
+        }
+        {
+            double v[6], l[6], r[6];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                v[s] = ue[s][P];
+                v[3 + s] = ue[s][1];
+            }
+            g.template exchange<6>(v, 1, l, r);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                ue[s][0] = l[s];
+                ue[s][P + 1] = r[3 + s];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int j = j0 + i;
+            const bool first = (j == 0), last = (j == n - 1);
+            double dd[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) dd[s] = ddx_edge1_point<true>(ue[s][i], ue[s][i + 1], ue[s][i + 2], first, last, rc);
+            const double pi = ue[1][i + 1];
+            const double Dsh = (dd[1] * dd[1]) / (pi * pi);     // D = (dpi/dx)^2 / pi^2, shared by the three fluxes
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const double flux = -Dsh * dd[s];
+                double D, c, DH, cH, thv;
+                flux_split_point(flux, ue[s][i + 1], dd[s], 1.0, 1.0, th, D, c, DH, cH, thv);
+                DE[s][i] = Q.a_turb * D + omt * (seeded ? DE[s][i] : D);
+                cE[s][i] = Q.a_turb * c + omt * (seeded ? cE[s][i] : c);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            store_chunk<P, false>(S_.DE[s] + off, n, j0, DE[s]);
+            store_chunk<P, false>(S_.cE[s] + off, n, j0, cE[s]);
+        }
+    }
+
+    // halos of H2 = DE, H3 = -cE and of the current profiles
+    double h2l[3], h3l[3], h2r[3], h3r[3];
+    {
+        double v[18], l[18], r[18];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            v[s] = DE[s][P - 1];
+            v[3 + s] = -cE[s][P - 1];
+            v[6 + s] = u[s][P];
+            v[9 + s] = DE[s][0];
+            v[12 + s] = -cE[s][0];
+            v[15 + s] = u[s][1];
+        }
+        g.template exchange<18>(v, 1, l, r);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            h2l[s] = l[s];
+            h3l[s] = l[3 + s];
+            u[s][0] = l[6 + s];
+            h2r[s] = r[9 + s];
+            h3r[s] = r[12 + s];
+            u[s][P + 1] = r[15 + s];
+        }
+    }
+    // the zero-padded shifts of the residual (tango/fieldgroups.py:139): nothing beyond either end
+    if (lane_first) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) u[s][0] = 0.0;
+    }
+
+    double um1[3][P];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) load_chunk<P, false>(S_.um1[s] + off, n, j0, um1[s], 0.0);
+    const double nu0 = Q.nu0[b];
+    double UL[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) UL[s] = Q.UL[s][b];
+
+    ChunkElim<P> eln;
+    BlockElim<2, P> elp;
+    double hm2[3], hm3[3], bm[3], h2c[3], h3c[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        h2c[s] = DE[s][0];
+        h3c[s] = -cE[s][0];
+        hm2[s] = lane_first ? 0.0 : (h2l[s] + h2c[s]) / 2.0;
+        hm3[s] = lane_first ? 0.0 : (h3l[s] + h3c[s]) / 2.0;
+        bm[s] = fbeta_point(hm2[s], hm3[s], rc.dx);
+    }
+    double mx[3] = {0.0, 0.0, 0.0}, ss[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int j = j0 + i;
+        const bool valid = j < n;
+        const bool last = (j == n - 1);
+        const int jc = valid ? j : n - 1;
+        // collisional coupling nu = nu0 / ((pi + pe)/n)^{3/2} from the current profiles (example :108-110)
+        const double q = u[1][i + 1] / u[0][i + 1] + u[2][i + 1] / u[0][i + 1];
+        const double nu = nu0 / (q * sqrt(q));
+        double A[3], B[3], C[3], f[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const double h2n = (i == P - 1) ? h2r[s] : DE[s][i < P - 1 ? i + 1 : 0];
+            const double h3n = (i == P - 1) ? h3r[s] : -cE[s][i < P - 1 ? i + 1 : 0];
+            const double hp2 = (h2c[s] + h2n) / 2.0;
+            const double hp3 = (h3c[s] + h3n) / 2.0;
+            const double bp = fbeta_point(hp2, hp3, rc.dx);
+            const double h6 = (s == 0) ? 0.0 : -nu;       // H6 = -nu for pi and pe (example :125, :144)
+            fd_row<true>(last, 1.0, um1[s][i], rc, UL[s], hm2[s], hm3[s], bm[s], hp2, hp3, bp, 0.0, h6, Q.H7[s][jc], A[s], B[s],
+                         C[s], f[s]);
+            if (!valid) {
+                A[s] = 0.0; B[s] = 1.0; C[s] = 0.0; f[s] = 0.0;
+            }
+            hm2[s] = hp2;
+            hm3[s] = hp3;
+            bm[s] = bp;
+            h2c[s] = h2n;
+            h3c[s] = h3n;
+        }
+        const double Gc = (valid && !last) ? -nu : 0.0;   // G = -H8 = -nu, zero on the Dirichlet row (JK_to_matrix_fd.py:126-129)
+        const double up[3] = {(j < n - 1) ? u[0][i + 2] : 0.0, (j < n - 1) ? u[1][i + 2] : 0.0, (j < n - 1) ? u[2][i + 2] : 0.0};
+        double r[3];
+        r[0] = A[0] * up[0] + B[0] * u[0][i + 1] + C[0] * u[0][i] - f[0];
+        r[1] = A[1] * up[1] + B[1] * u[1][i + 1] + C[1] * u[1][i] + Gc * u[2][i + 1] - f[1];
+        r[2] = A[2] * up[2] + B[2] * u[2][i + 1] + C[2] * u[2][i] + Gc * u[1][i + 1] - f[2];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            ss[s] += valid ? r[s] * r[s] : 0.0;
+            mx[s] = fmax(mx[s], valid ? fabs(f[s]) : 0.0);
+        }
+        eln.push(i, C[0], B[0], A[0], f[0]);
+        Mat<2> Cm = mat_zero<2>(), Bm, Am = mat_zero<2>();
+        Vec<2> d;
+        Cm.m[0][0] = C[1];
+        Cm.m[1][1] = C[2];
+        Am.m[0][0] = A[1];
+        Am.m[1][1] = A[2];
+        Bm.m[0][0] = B[1];
+        Bm.m[0][1] = Gc;
+        Bm.m[1][0] = Gc;
+        Bm.m[1][1] = B[2];
+        d.v[0] = f[1];
+        d.v[1] = f[2];
+        elp.push(i, Cm, Bm, Am, d);
+    }
+    double tot = 0.0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const double m = g.max(mx[s]);
+        tot += g.sum(ss[s]) / (m * m);
+    }
+    const double rms = sqrt(1.0 / (3.0 * (double)n) * tot);
+
+    double xn[P];
+    Vec<2> xp[P];
+    eln.finish(g, xn);
+    elp.finish(g, xp);
+    double xi[P], xe[P];
+    int bad = 0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        xi[i] = xp[i].v[0];
+        xe[i] = xp[i].v[1];
+        if (j0 + i < n) bad |= !(isfinite(xn[i]) && xn[i] >= 0.0 && isfinite(xi[i]) && xi[i] >= 0.0 && isfinite(xe[i]) && xe[i] >= 0.0);
+    }
+    store_chunk<P, false>(S_.u[0] + off, n, j0, xn);
+    store_chunk<P, false>(S_.u[1] + off, n, j0, xi);
+    store_chunk<P, false>(S_.u[2] + off, n, j0, xe);
+    bad = g.any(bad | ((eln.singular | elp.singular) << 1));
+    if (t == 0) {
+        int ns = st;
+        if (!Q.frozen_turb) {
+            if (S_.err && it < S_.err_stride) S_.err[b * S_.err_stride + it] = rms;
+            S_.iters[b] = it + 1;
+            ns |= TG_ST_SEEDED;
+            if (!Q.fixed_count && rms < Q.tol) ns |= TG_ST_CONVERGED;
+        }
+        if (bad & 1) ns |= TG_ST_INVALID;
+        if (bad & 2) ns |= TG_ST_SINGULAR;
+        S_.status[b] = ns;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// dispatch on the number of lanes per profile
+// ------------------------------------------------------------------------------------------
+template <template <int, class> class Launcher, class... Args>
+int dispatch_block(int64_t nb, int n, int max_lanes, hipStream_t s, Args... args) {
+    const int lanes = pow2_at_least((n + PB - 1) / PB);
+    if (lanes > max_lanes) return fail(TG_ERR_UNSUPPORTED, "grid too large for the block-tridiagonal kernels%s");
+    if (lanes <= 8) return Launcher<PB, WaveGroup<8>>::go(nb, n, s, args...);
+    if (lanes == 16) return Launcher<PB, WaveGroup<16>>::go(nb, n, s, args...);
+    if (lanes == 32) return Launcher<PB, WaveGroup<32>>::go(nb, n, s, args...);
+    if (lanes == 64) return Launcher<PB, WaveGroup<64>>::go(nb, n, s, args...);
+    if (lanes == 128) return Launcher<PB, BlockGroup<128>>::go(nb, n, s, args...);
+    if (lanes == 256) return Launcher<PB, BlockGroup<256>>::go(nb, n, s, args...);
+    if (lanes == 512) return Launcher<PB, BlockGroup<512>>::go(nb, n, s, args...);
+    return Launcher<PB, BlockGroup<1024>>::go(nb, n, s, args...);
+}
+
+template <int P, class G>
+struct PairLauncher {
+    static int go(int64_t nb, int n, hipStream_t s, PairArgs a, int32_t *status) {
+        int grid, block;
+        size_t lds;
+        geometry<G>(nb, grid, block, lds, RowPack<2>::N);
+        hipLaunchKernelGGL((pair_solve_kernel<P, G>), dim3(grid), dim3(block), lds, s, a, nb, n, status);
+        return launch_check();
+    }
+};
+
+template <int P, class G>
+struct Block3Launcher {
+    static int go(int64_t nb, int n, hipStream_t s, const double *Cb, const double *Bb, const double *Ab, const double *d,
+                  double *x, int32_t *status) {
+        int grid, block;
+        size_t lds;
+        geometry<G>(nb, grid, block, lds, RowPack<3>::N);
+        hipLaunchKernelGGL((block3_solve_kernel<P, G>), dim3(grid), dim3(block), lds, s, Cb, Bb, Ab, d, x, nb, n, status);
+        return launch_check();
+    }
+};
+
+template <int P, class G>
+struct Picard3fLauncher {
+    static int go(int64_t nb, int n, hipStream_t s, const tg_state_3f *st, const tg_params_3f *q) {
+        int grid, block;
+        size_t lds;
+        geometry<G>(nb, grid, block, lds, 18);
+        hipLaunchKernelGGL((picard_3f_kernel<P, G>), dim3(grid), dim3(block), lds, s, *st, *q);
+        return launch_check();
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int tg_pair_solve(const double *AU, const double *BU, const double *CU, const double *DU, const double *GW, const double *AW,
+                  const double *BW, const double *CW, const double *DW, const double *GU, double *U, double *W, int64_t nb,
+                  int64_t n, int32_t *status, tg_stream stream) {
+    if (nb < 0 || n < 1) return fail(TG_ERR_ARG, "bad dimensions%s");
+    if (!AU || !BU || !CU || !DU || !GW || !AW || !BW || !CW || !DW || !GU || !U || !W) return fail(TG_ERR_ARG, "NULL array%s");
+    if (nb == 0) return TG_OK;
+    PairArgs a{AU, BU, CU, DU, GW, AW, BW, CW, DW, GU, U, W};
+    return dispatch_block<PairLauncher>(nb, (int)n, 1024, S(stream), a, status);
+}
+
+int tg_block3_solve(const double *Cb, const double *Bb, const double *Ab, const double *d, double *x, int64_t nb, int64_t n,
+                    int32_t *status, tg_stream stream) {
+    if (nb < 0 || n < 1) return fail(TG_ERR_ARG, "bad dimensions%s");
+    if (!Cb || !Bb || !Ab || !d || !x) return fail(TG_ERR_ARG, "NULL array%s");
+    if (nb == 0) return TG_OK;
+    return dispatch_block<Block3Launcher>(nb, (int)n, 512, S(stream), Cb, Bb, Ab, d, x, status);
+}
+
+int tg_picard_3f_step(const tg_state_3f *st, const tg_params_3f *q, tg_stream stream) {
+    if (!st || !q) return fail(TG_ERR_ARG, "NULL state or params%s");
+    if (st->nb < 0 || st->n < 3) return fail(TG_ERR_ARG, "bad dimensions%s");
+    for (int s = 0; s < 3; ++s) {
+        if (!st->u[s] || !st->um1[s] || !st->uE[s] || !st->DE[s] || !st->cE[s]) return fail(TG_ERR_ARG, "NULL state array%s");
+        if (!q->UL[s] || !q->H7[s]) return fail(TG_ERR_ARG, "UL and H7 are required for the three fields%s");
+    }
+    if (!st->status || !st->iters || !q->nu0) return fail(TG_ERR_ARG, "NULL status, iters or nu0%s");
+    if (st->err && st->err_stride <= 0) return fail(TG_ERR_ARG, "err_stride must be positive%s");
+    if (st->nb == 0) return TG_OK;
+    return dispatch_block<Picard3fLauncher>(st->nb, (int)st->n, 1024, S(stream), st, q);
+}
+
+}  // extern "C"

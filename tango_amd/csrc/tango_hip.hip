@@ -15,80 +15,15 @@
 #include "../../include/tango_hip.h"
 #include "tg_assemble.h"
 #include "tg_comm.h"
+#include "tg_host.h"
+#include "tg_io.h"
 #include "tg_solve.h"
+
+thread_local char tg_err_buf[512] = "";
 
 namespace {
 
-thread_local char g_err[512] = "";
-
-int fail(int code, const char *fmt, const char *a = "") {
-    snprintf(g_err, sizeof(g_err), fmt, a);
-    return code;
-}
-
-#define TG_HIP(call)                                                        \
-    do {                                                                    \
-        hipError_t e_ = (call);                                             \
-        if (e_ != hipSuccess) return fail(TG_ERR_HIP, #call ": %s", hipGetErrorString(e_)); \
-    } while (0)
-
-inline hipStream_t S(tg_stream s) { return reinterpret_cast<hipStream_t>(s); }
-
-int launch_check() {
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(TG_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
-    return TG_OK;
-}
-
 using namespace tg;
-
-// ------------------------------------------------------------------------------------------
-// Row I/O: lane t of a group reads / writes its P consecutive points of a profile row.
-// ------------------------------------------------------------------------------------------
-// FULL: the row is exactly T*P points and 16-byte aligned (n even), so every lane takes the
-// vector path with no bounds checks.
-template <int P, bool FULL>
-__device__ __forceinline__ void load_chunk(const double *__restrict__ row, int n, int j0, double *v, double fill) {
-    if constexpr (P % 2 == 0) {
-        if (FULL || (j0 + P <= n && ((reinterpret_cast<uintptr_t>(row + j0) & 15) == 0))) {
-#ifdef TG_EXPERIMENT_COALESCED
-            const double2 *q = reinterpret_cast<const double2 *>(row) + (threadIdx.x & 63);
-#define TG_QI(i) ((i) * 64)
-#else
-            const double2 *q = reinterpret_cast<const double2 *>(row + j0);
-#define TG_QI(i) (i)
-#endif
-#pragma unroll
-            for (int i = 0; i < P / 2; ++i) {
-                double2 w = q[TG_QI(i)];
-                v[2 * i] = w.x;
-                v[2 * i + 1] = w.y;
-            }
-            return;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < P; ++i) v[i] = (j0 + i < n) ? row[j0 + i] : fill;
-}
-
-template <int P, bool FULL>
-__device__ __forceinline__ void store_chunk(double *__restrict__ row, int n, int j0, const double *v) {
-    if constexpr (P % 2 == 0) {
-        if (FULL || (j0 + P <= n && ((reinterpret_cast<uintptr_t>(row + j0) & 15) == 0))) {
-#ifdef TG_EXPERIMENT_COALESCED
-            double2 *q = reinterpret_cast<double2 *>(row) + (threadIdx.x & 63);
-#else
-            double2 *q = reinterpret_cast<double2 *>(row + j0);
-#endif
-#pragma unroll
-            for (int i = 0; i < P / 2; ++i) q[TG_QI(i)] = make_double2(v[2 * i], v[2 * i + 1]);
-            return;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-        if (j0 + i < n) row[j0 + i] = v[i];
-}
 
 // ------------------------------------------------------------------------------------------
 // Tridiagonal solve, point-fastest: one lane group per profile.
@@ -566,12 +501,6 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
 // ------------------------------------------------------------------------------------------
 // Launch geometry: lanes per profile for a grid of n points at P points per lane.
 // ------------------------------------------------------------------------------------------
-int pow2_at_least(int v) {
-    int p = 1;
-    while (p < v) p <<= 1;
-    return p;
-}
-
 int grid_1d(int64_t total, int block) {
     int64_t g = (total + block - 1) / block;
     const int64_t cap = 256 * 32;  // CUs x resident blocks; grid-stride beyond that
@@ -592,20 +521,6 @@ int dispatch_group(int64_t nb, int n, hipStream_t s, Args... args) {
     if (lanes == 1024) return Launcher<P, BlockGroup<1024>>::go(nb, n, s, args...);
     if (n <= 16384) return Launcher<16, BlockGroup<1024>>::go(nb, n, s, args...);
     return fail(TG_ERR_UNSUPPORTED, "point-fastest solvers support n <= 16384%s");
-}
-
-template <class G>
-void geometry(int64_t nb, int &grid, int &block, size_t &lds) {
-    if (G::kBlock) {
-        block = G::T;
-        grid = (int)nb;
-        lds = sizeof(double) * 8 * G::T;
-    } else {
-        block = 256;
-        const int ppb = 256 / G::T;
-        grid = (int)((nb + ppb - 1) / ppb);
-        lds = 0;
-    }
 }
 
 template <int P, class G>
@@ -660,7 +575,7 @@ struct Picard1fLauncher {
 extern "C" {
 
 int tg_version(void) { return 100; }
-const char *tg_last_error(void) { return g_err; }
+const char *tg_last_error(void) { return tg_err_buf; }
 
 int tg_device_count(int *count) {
     if (!count) return fail(TG_ERR_ARG, "count is NULL%s");

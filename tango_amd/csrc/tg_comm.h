@@ -33,6 +33,15 @@ struct WaveGroup {
         double r = __shfl_down(v, (unsigned)h, LPP);
         return (t_ + h < LPP) ? r : fill;
     }
+    // CNT values from the lanes t-h (l) and t+h (r), zeros where there is no such lane
+    template <int CNT>
+    __device__ void exchange(const double (&v)[CNT], int h, double (&l)[CNT], double (&r)[CNT]) const {
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            l[q] = from_left(v[q], h, 0.0);
+            r[q] = from_right(v[q], h, 0.0);
+        }
+    }
     __device__ double sum(double v) const {
 #pragma unroll
         for (int m = LPP >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, LPP);
@@ -74,7 +83,7 @@ struct WaveGroup {
     }
 };
 
-// One workgroup of T_ threads per profile.  `lds` must hold at least 8*T_ doubles.
+// One workgroup of T_ threads per profile.  `lds` must hold at least 8*T_ doubles (CNT*T_ for exchange<CNT>).
 template <int T_>
 struct BlockGroup {
     static constexpr int T = T_;
@@ -99,6 +108,19 @@ struct BlockGroup {
         double r = (t_ + h < T_) ? lds_[t_ + h] : fill;
         __syncthreads();
         return r;
+    }
+    // CNT values from the threads t-h (l) and t+h (r), zeros where there is none; needs CNT*T_ doubles of LDS
+    template <int CNT>
+    __device__ void exchange(const double (&v)[CNT], int h, double (&l)[CNT], double (&r)[CNT]) const {
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) lds_[q * T_ + t_] = v[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            l[q] = (t_ >= h) ? lds_[q * T_ + t_ - h] : 0.0;
+            r[q] = (t_ + h < T_) ? lds_[q * T_ + t_ + h] : 0.0;
+        }
+        __syncthreads();
     }
     __device__ double sum(double v) const {
 #pragma unroll

@@ -1,0 +1,54 @@
+// Host-side helpers shared by the translation units of libtango_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tango_hip.h"
+
+extern thread_local char tg_err_buf[512];
+
+namespace {
+
+inline int fail(int code, const char *fmt, const char *a = "") {
+    snprintf(tg_err_buf, sizeof(tg_err_buf), fmt, a);
+    return code;
+}
+
+#define TG_HIP(call)                                                        \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) return fail(TG_ERR_HIP, #call ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+inline hipStream_t S(tg_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int launch_check() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(TG_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return TG_OK;
+}
+
+inline int pow2_at_least(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// Launch geometry of a lane-group kernel: WaveGroup kernels use 256-thread workgroups holding 256/T
+// profiles; BlockGroup kernels one workgroup of T threads per profile with lds_doubles_per_thread*T doubles.
+template <class G>
+inline void geometry(int64_t nb, int &grid, int &block, size_t &lds, int lds_doubles_per_thread = 8) {
+    if (G::kBlock) {
+        block = G::T;
+        grid = (int)nb;
+        lds = sizeof(double) * (size_t)lds_doubles_per_thread * G::T;
+    } else {
+        block = 256;
+        const int ppb = 256 / G::T;
+        grid = (int)((nb + ppb - 1) / ppb);
+        lds = 0;
+    }
+}
+
+}  // namespace

@@ -1,1 +1,2 @@
 from . import shestakov_nonlinear_diffusion  # noqa: F401
+from . import threefield  # noqa: F401

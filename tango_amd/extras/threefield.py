@@ -1,0 +1,191 @@
+"""Three-field analytic problem n, pi, pe with nonlinear collisional coupling, packaged from
+examples/shestakov_threefield_nonlinearnu.py:52-149 of the reference:
+
+    dn/dt  + dG/dx  = Sn          G  = -D dn/dx,   D = (dpi/dx)^2 / pi^2
+    dpi/dt + dQi/dx = Si - nu (pi - pe)
+    dpe/dt + dQe/dx = Se - nu (pe - pi)       nu = nu0 / (pi/n + pe/n)^(3/2)
+
+n is solved on its own, pi and pe as a pair-coupled system.  The classes below are the example's flux model and
+compute_all_H callbacks; used together with solver.Solver they are recognised and run by the fused
+three-field kernel (tg_picard_3f_step), one launch per Picard iteration for a whole ensemble (nu0 and the three
+right boundary values may be one value per profile)."""
+import ctypes as C
+
+import numpy as np
+
+from .. import _hip as H
+from .. import derivatives, multifield
+
+LABELS = ('n', 'pi', 'pe')
+
+
+class ShestakovThreeFieldFluxModel(object):
+    fused_flux_model = 'threefield_nonlinear_nu'
+
+    def __init__(self, dx):
+        self.dx = dx
+
+    def get_flux(self, profiles):
+        n, pi, pe = profiles['n'], profiles['pi'], profiles['pe']
+        d = derivatives.dx_centered_difference_edge_first_order
+        dndx, dpidx, dpedx = d(n, self.dx), d(pi, self.dx), d(pe, self.dx)
+        D = dpidx ** 2 / pi ** 2
+        return {'n': -D * dndx, 'pi': -D * dpidx, 'pe': -D * dpedx}
+
+
+def _box(x, S0, delta):
+    S = np.zeros_like(x)
+    S[x < delta] = S0
+    return S
+
+
+def source_n(x, S0=8, delta=0.3):
+    return _box(x, S0, delta)
+
+
+def source_i(x, S0=1, delta=0.1):
+    return _box(x, S0, delta)
+
+
+def source_e(x, S0=3, delta=0.4):
+    S = np.zeros_like(x)
+    ind = x < delta
+    S[ind] = S0 * x[ind]
+    return S
+
+
+def calc_nu(nu0, n, pi, pe):
+    nu0 = np.asarray(nu0, dtype=float)
+    if nu0.ndim:
+        nu0 = nu0[..., None]
+    return nu0 / ((pi / n + pe / n) ** (3 / 2))
+
+
+class ComputeAllH_n(object):
+    fused_role = 'n'
+
+    def __call__(self, t, x, profiles, HCoeffsTurb):
+        return multifield.HCoefficients(H1=np.ones_like(x), H7=source_n(x)) + HCoeffsTurb
+
+
+class _ComputeAllH_p(object):
+    source = None
+
+    def __init__(self, nu0):
+        self.nu0 = nu0
+
+    def __call__(self, t, x, profiles, HCoeffsTurb):
+        nu = calc_nu(self.nu0, profiles['n'], profiles['pi'], profiles['pe'])
+        H = multifield.HCoefficients(H1=np.ones_like(x), H6=-nu, H7=type(self).source(x), H8=nu)
+        return H + HCoeffsTurb
+
+
+class ComputeAllH_pi(_ComputeAllH_p):
+    fused_role = 'pi'
+    source = staticmethod(source_i)
+
+
+class ComputeAllH_pe(_ComputeAllH_p):
+    fused_role = 'pe'
+    source = staticmethod(source_e)
+
+
+def plan(s):
+    """Fused-path runner for solver.Solver `s`, or None if the fields are not exactly this problem."""
+    by_label = {f.label: f for f in s.fields}
+    if sorted(by_label) != sorted(LABELS):
+        return None
+    fn, fi, fe = (by_label[k] for k in LABELS)
+    roles = [getattr(f.compute_all_H, 'fused_role', None) for f in (fn, fi, fe)]
+    if roles != list(LABELS) or fn.coupledTo is not None or fi.coupledTo != 'pe' or fe.coupledTo != 'pi':
+        return None
+    if not np.array_equal(np.asarray(fi.compute_all_H.nu0), np.asarray(fe.compute_all_H.nu0)):
+        return None
+    params = [f.lodestroMethod.get_ewma_params() for f in (fn, fi, fe)]
+    thetas = [f.lodestroMethod._fluxSplitter.thetaParams for f in (fn, fi, fe)]
+    if len(set(params)) != 1 or any(dict(th) != dict(thetas[0]) for th in thetas):
+        return None
+    return Fused3F(s, (fn, fi, fe))
+
+
+class Fused3F(object):
+    """Device-resident three-field ensemble stepped by tg_picard_3f_step."""
+
+    def __init__(self, s, fields):
+        self.fields = fields
+        u0 = [np.atleast_2d(np.asarray(s.profiles[f.label], dtype=np.float64)) for f in fields]
+        self.nb, self.n = u0[0].shape
+        nb, n = self.nb, self.n
+        D = H.DeviceArray
+        self.u = [D.from_host(v) for v in u0]
+        self.um1 = [D.from_host(np.atleast_2d(np.asarray(f.profile_mminus1, dtype=np.float64))) for f in fields]
+        self.uE = [D((nb, n), zero=True) for _ in range(3)]
+        self.DE = [D((nb, n), zero=True) for _ in range(3)]
+        self.cE = [D((nb, n), zero=True) for _ in range(3)]
+        self.status = D((nb,), np.int32, zero=True)
+        self.iters = D((nb,), np.int32, zero=True)
+        self.err = D((nb, s.maxIterations), zero=True)
+        self.counts = D((4,), np.int64, zero=True)
+        self.UL = [D.from_host(np.broadcast_to(np.asarray(f.rightBC, dtype=np.float64), (nb,))) for f in fields]
+        self.nu0 = D.from_host(np.broadcast_to(np.asarray(fields[1].compute_all_H.nu0, dtype=np.float64), (nb,)))
+        x = np.asarray(s.x, dtype=np.float64)
+        self.H7 = [D.from_host(src(x)) for src in (source_n, source_i, source_e)]
+        P3 = H._p * 3
+        ptrs = lambda arrs: P3(*[a.ptr for a in arrs])
+        self.state = H.State3F(nb, n, ptrs(self.u), ptrs(self.um1), ptrs(self.uE), ptrs(self.DE), ptrs(self.cE),
+                               self.status.ptr, self.iters.ptr, self.err.ptr, s.maxIterations)
+        self._ptrs = ptrs
+
+    def params(self, s):
+        m = self.fields[0].lodestroMethod
+        a_turb, a_prof = m.get_ewma_params()
+        tp = m._fluxSplitter.thetaParams
+        q = H.Params3F()
+        q.dt, q.dx, q.a_turb, q.a_prof = float(s.dt), float(s.dx), float(a_turb), float(a_prof)
+        q.Dmin, q.Dmax, q.dpdx_thr, q.tol = float(tp['Dmin']), float(tp['Dmax']), float(tp['dpdxThreshold']), float(s.tol)
+        q.UL, q.H7, q.nu0 = self._ptrs(self.UL), self._ptrs(self.H7), self.nu0.ptr
+        q.fixed_count, q.frozen_turb, q.outer_count = 0, 0, 0
+        return q
+
+    def run_timestep(self, s):
+        q = self.params(s)
+        if s.m > 1:
+            for a, b in zip(self.um1, self.u):
+                a.copy_from(b)
+            self.status.set((self.status.to_host() & H.ST_SEEDED).astype(np.int32))
+            H.check(H.lib.tg_memset(self.iters.ptr, 0, self.iters.nbytes, H.stream()))
+            H.check(H.lib.tg_memset(self.err.ptr, 0, self.err.nbytes, H.stream()))
+        inner = s.innerIterationMaxCount if s.useInnerIteration else 0
+        hist = s.profilesAllIterations
+        done = s.iterationNumber
+        while done < s.maxIterations:
+            q.frozen_turb, q.outer_count = 0, 0
+            H.check(H.lib.tg_picard_3f_step(C.byref(self.state), C.byref(q), H.stream()))
+            done += 1
+            q.frozen_turb, q.outer_count = 1, done
+            for _ in range(inner):      # inner iteration with frozen turbulent coefficients (tango/solver.py:274-309)
+                H.check(H.lib.tg_picard_3f_step(C.byref(self.state), C.byref(q), H.stream()))
+            if hist is not None:
+                for f, d in zip(self.fields, self.u):
+                    snap = d.to_host()
+                    hist[f.label][done - 1] = snap if s.batched else snap[0]
+            if done % s.iterationsPerCheck == 0 or hist is not None or done == s.maxIterations:
+                H.check(H.lib.tg_status_reduce(self.status.ptr, self.nb, self.counts.ptr, H.stream()))
+                if int(self.counts.to_host()[0]) == 0:
+                    break
+        self.finish(s)
+
+    def finish(self, s):
+        status, iters, err = self.status.to_host(), self.iters.to_host(), self.err.to_host()
+        s.iterationsPerProfile = iters.astype(np.int64)
+        s.iterationNumber = int(iters.max())
+        s.countStoredIterations = s.iterationNumber
+        s.converged = bool(np.all(status & H.ST_CONVERGED))
+        s.solutionError = bool(np.any(status & H.ST_INVALID))
+        s.profileStatus = status
+        pick = (lambda a: a) if s.batched else (lambda a: a[0])
+        s.errHistory = err if s.batched else err[0].copy()
+        s.profiles = {f.label: pick(d.to_host()) for f, d in zip(self.fields, self.u)}
+        for k, f in enumerate(self.fields):
+            f.lodestroMethod.set_ewma_iterates(pick(self.uE[k].to_host()), pick(self.DE[k].to_host()),
+                                               pick(self.cE[k].to_host()))

@@ -372,7 +372,7 @@ def is_unacceptable_one_profile(oldProfile, newProfile, maxFractionalChange=0.2,
 # ---------------------------------------------------------------------- fused path
 def _plan_fused(s):
     """Return a fused-path runner when the problem is one the fused kernels implement, else None."""
-    if (s.user_control_func is not None or s.useTreadLightly or s.useTreadInitially or s.useInnerIteration
+    if (s.user_control_func is not None or s.useTreadLightly or s.useTreadInitially
             or s.saveFluxesInMemory or s.maxIterationsPerSet != np.inf):
         return None
     call = s.compute_all_H_all_fields
@@ -389,7 +389,7 @@ def _plan_fused(s):
         if sp.ftheta != sp._default_ftheta or np.ndim(sp.gxxAvg) or np.ndim(sp.gradxAvg) or sp.gxxAvg != 1 or sp.gradxAvg != 1:
             return None
     model = getattr(th.fluxModel, 'fused_flux_model', None)
-    if model == 'shestakov' and len(s.fields) == 1 and s.fields[0].coupledTo is None \
+    if model == 'shestakov' and len(s.fields) == 1 and s.fields[0].coupledTo is None and not s.useInnerIteration \
             and getattr(s.fields[0].compute_all_H, 'fused_source', None) is not None \
             and th.dxTurbGrid == s.dx and th.fluxModel.dx == s.dx:
         return _Fused1F(s)

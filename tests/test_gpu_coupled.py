@@ -1,0 +1,173 @@
+"""Coupled-field kernels: the pair-coupled (2x2 block) solve, the 3x3 block-tridiagonal solve and the fused
+three-field Picard iteration, against the reference's golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+from oracle import tango_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope='module')
+def tango():
+    import tango_amd
+    assert tango_amd.device_count() > 0
+    return tango_amd
+
+
+def test_pair_golden(tango, golden):
+    """tests/test_JK_to_matrix_fd.py:10-76 and tests/test_fieldgroups.py:68-114 of the reference."""
+    g = golden('g3_pair')
+    z = np.zeros_like(g['x'])
+    kw = {f'J{i}': g[f'J{i}'] for i in (1, 2, 3, 6, 7, 8)}
+    kw.update({f'K{i}': g[f'K{i}'] for i in (1, 2, 3, 6, 7, 8)})
+    Ue, We = tango.JK_to_matrix_fd.JK_to_matrix(float(g['dt']), float(g['dx']), (float(g['UL']), float(g['WL'])), (z, z), **kw)
+    for got, k in zip(Ue, ('AU', 'BU', 'CU', 'DU', 'GW')):
+        assert relerr(got, g[k]) < 1e-14, k
+    for got, k in zip(We, ('AW', 'BW', 'CW', 'DW', 'GU')):
+        assert relerr(got, g[k]) < 1e-14, k
+    U, W = tango.JK_to_matrix_fd.solve(Ue, We)
+    assert relerr(U, g['U']) < TOL and relerr(W, g['W']) < TOL
+    assert np.allclose(U, g['Uan'], rtol=1e-4, atol=1e-4) and np.allclose(W, g['Wan'], rtol=1e-4, atol=1e-4)
+    with pytest.raises(AssertionError):
+        tango.JK_to_matrix_fd.JK_to_matrix(1.0, 0.1, (1, 1), (z, z), J2=g['J2'], K1=g['K1'])
+    # field-group chain and residual (golden: perturbed profiles with the same matrix)
+    pfg = tango.fieldgroups.PairCoupledFieldGroup('a', 'b')
+    JK = tango.fieldgroups.JKCoefficients(**kw)
+    meq = pfg.Hcoeffs_to_matrix_eqn(float(g['dt']), float(g['dx']), (float(g['UL']), float(g['WL'])), (z, z), JK)
+    sol = pfg.solve_matrix_eqn(meq)
+    assert relerr(sol['a'], g['U']) < TOL and relerr(sol['b'], g['W']) < TOL
+    res = pfg.calculate_residual(meq, {'a': g['res_U_in'], 'b': g['res_W_in']})
+    # the residual cancels terms of size max|B| max|u| down to max|res|: its rounding bound, not 1e-10, is the bar
+    for k, u, B, ref in (('a', 'res_U_in', 'BU', 'res_U'), ('b', 'res_W_in', 'BW', 'res_W')):
+        bound = 4 * np.finfo(float).eps * np.max(np.abs(g[B])) * np.max(np.abs(g[u])) / np.max(np.abs(g[ref]))
+        assert relerr(res[k], g[ref]) < bound, (k, bound)
+
+
+@pytest.mark.parametrize('n', [1, 2, 5, 16, 100, 255, 256, 500, 1000, 2048, 4096])
+def test_pair_solve_random(tango, n):
+    rng = np.random.default_rng(100 + n)
+    nb = 3
+    def dom():
+        A = rng.uniform(-1, 1, (nb, n)); C = rng.uniform(-1, 1, (nb, n)); G = rng.uniform(-0.5, 0.5, (nb, n))
+        B = np.abs(A) + np.abs(C) + np.abs(G) + rng.uniform(0.1, 1, (nb, n))
+        return A, B, C, rng.normal(size=(nb, n)), G
+    U, W = dom(), dom()
+    ru, rw = orc.pair_solve(U, W)
+    gu, gw = tango.JK_to_matrix_fd.solve(tango.JK_to_matrix_fd.MatEqnCoeffs(*U), tango.JK_to_matrix_fd.MatEqnCoeffs(*W))
+    assert relerr(gu, ru) < 1e-12 and relerr(gw, rw) < 1e-12
+
+
+@pytest.mark.parametrize('n', [1, 3, 4, 17, 64, 200, 256, 700, 2048])
+def test_block3_solve(tango, n):
+    """3x3 block-tridiagonal solve against a dense solve; also the reference's structure (n uncoupled, pi<->pe
+    coupled only through the diagonal block) as a special case."""
+    from tango_amd import _ops
+    rng = np.random.default_rng(7 * n)
+    nb = 2 if n > 500 else 4
+    Cb = rng.uniform(-1, 1, (nb, n, 3, 3)); Ab = rng.uniform(-1, 1, (nb, n, 3, 3))
+    Bb = rng.uniform(-1, 1, (nb, n, 3, 3)) + 8 * np.eye(3)
+    d = rng.normal(size=(nb, n, 3))
+    x = _ops.block3_solve(Cb, Bb, Ab, d)
+    for b in range(nb):
+        ref = orc.block3_dense_solve(Cb[b], Bb[b], Ab[b], d[b])
+        assert relerr(x[b], ref) < 1e-11
+    # reference structure: scalar field 0, pair (1,2) with diagonal off-diagonal blocks
+    a = rng.uniform(-1, 1, (3, n)); c = rng.uniform(-1, 1, (3, n)); gg = rng.uniform(-0.5, 0.5, (2, n))
+    bd = np.abs(a) + np.abs(c) + 1.0
+    rhs = rng.normal(size=(3, n))
+    Cb1 = np.zeros((n, 3, 3)); Ab1 = np.zeros((n, 3, 3)); Bb1 = np.zeros((n, 3, 3))
+    for k in range(3):
+        Cb1[:, k, k] = c[k]; Ab1[:, k, k] = a[k]; Bb1[:, k, k] = bd[k]
+    Bb1[:, 1, 2] = gg[0]; Bb1[:, 2, 1] = gg[1]
+    x1 = _ops.block3_solve(Cb1, Bb1, Ab1, rhs.T.copy())
+    u0 = orc.tridiag_solve(a[0], bd[0], c[0], rhs[0])
+    u1, u2 = orc.pair_solve((a[1], bd[1], c[1], rhs[1], gg[0]), (a[2], bd[2], c[2], rhs[2], gg[1]))
+    assert relerr(x1[:, 0], u0) < 1e-12 and relerr(x1[:, 1], u1) < 1e-12 and relerr(x1[:, 2], u2) < 1e-12
+
+
+def make_3f_solver(tango, N, nu0, BCs, tol=1e-9, maxit=1000, inner=0, fused=True, ic=None, **kw):
+    T = tango.extras.threefield
+    dx = 1 / (N - 1); x = np.arange(N) * dx
+    th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
+    ic = (1 - 0.5 * x) if ic is None else ic
+    cbs = [T.ComputeAllH_n(), T.ComputeAllH_pi(nu0), T.ComputeAllH_pe(nu0)]
+    if not fused:     # plain callables -> generic path
+        cbs = [(lambda cb: (lambda t, xx, p, HT: cb(t, xx, p, HT)))(cb) for cb in cbs]
+    lms = [tango.lodestro_method.lm(0.3, 0.3, th) for _ in range(3)]
+    F = tango.multifield.Field
+    fields = [F(label='n', rightBC=BCs[0], profile_mminus1=1.0 * ic, compute_all_H=cbs[0], lodestroMethod=lms[0]),
+              F(label='pi', rightBC=BCs[1], profile_mminus1=1.0 * ic, compute_all_H=cbs[1], lodestroMethod=lms[1], coupledTo='pe'),
+              F(label='pe', rightBC=BCs[2], profile_mminus1=1.0 * ic, compute_all_H=cbs[2], lodestroMethod=lms[2], coupledTo='pi')]
+    tango.multifield.check_fields_initialize(fields)
+    call = tango.multifield.ComputeAllHAllFields(fields, tango.lodestro_method.TurbulenceHandler(dx, x, T.ShestakovThreeFieldFluxModel(dx)))
+    return tango.solver.Solver(1, x, np.array([0, 1e6]), maxit, tol, call, fields, useInnerIteration=inner > 0,
+                               innerIterationMaxCount=max(inner, 1), **kw), lms
+
+
+def test_threefield_fused_matches_reference(tango, golden):
+    g = golden('g9_threefield')
+    s, lms = make_3f_solver(tango, 500, 2.2, (2, 0.1, 0.3))
+    assert s._fused is not None
+    while s.ok:
+        s.take_timestep()
+    assert s.reachedEnd and s.converged
+    assert abs(len(s.errHistoryFinal) - int(g['N500_iters'])) <= 1
+    k = min(len(s.errHistoryFinal), int(g['N500_iters']))
+    assert np.allclose(s.errHistoryFinal[:k], g['N500_err'][:k], rtol=1e-6, atol=5e-12)   # rounding floor of the rms residual
+    for lab in ('n', 'pi', 'pe'):
+        assert relerr(s.profiles[lab], g[f'N500_{lab}']) < TOL
+        assert relerr(s.profilesAllIterations[lab][0], g[f'N500_it0_{lab}']) < TOL
+        assert relerr(s.profilesAllIterations[lab][10], g[f'N500_it10_{lab}']) < TOL
+    # values quoted for this problem
+    assert abs(s.profiles['n'][0] - 3.943314) < 1e-6 and abs(s.profiles['pi'][0] - 0.325379) < 1e-6
+    if len(s.errHistoryFinal) == int(g['N500_iters']):
+        assert relerr(lms[1]._EWMATurbD._yEWMA_lminus1, g['N500_ewma_pi'][0]) < TOL
+
+
+def test_threefield_inner_iteration(tango, golden):
+    g = golden('g9_threefield')
+    s, _ = make_3f_solver(tango, 500, 2.2, (2, 0.1, 0.3), inner=2)
+    assert s._fused is not None
+    while s.ok:
+        s.take_timestep()
+    assert s.converged and abs(len(s.errHistoryFinal) - int(g['inner_iters'])) <= 1
+    for lab in ('n', 'pi', 'pe'):
+        assert relerr(s.profiles[lab], g[f'inner_{lab}']) < TOL
+        assert relerr(s.profilesAllIterations[lab][0], g[f'inner_it0_{lab}']) < TOL
+
+
+def test_threefield_generic_path(tango, golden):
+    """User-style callbacks: n through the scalar kernels, (pi, pe) through JK_to_matrix + the pair solve."""
+    g = golden('g9_threefield')
+    s, _ = make_3f_solver(tango, 500, 2.2, (2, 0.1, 0.3), fused=False, maxit=12, tol=1e-30)
+    assert s._fused is None
+    s.take_timestep()
+    for lab in ('n', 'pi', 'pe'):
+        assert relerr(s.profilesAllIterations[lab][0], g[f'N500_it0_{lab}']) < TOL
+        assert relerr(s.profilesAllIterations[lab][10], g[f'N500_it10_{lab}']) < TOL
+    assert np.allclose(s.errHistoryFinal, g['N500_err'][:12], rtol=1e-6, atol=1e-12)
+
+
+def test_threefield_ensemble(tango, golden):
+    """An ensemble with per-profile nu0 and boundary values: member 0 is the example problem, member 1 the
+    second golden trajectory (N = 512), the others are checked against the CPU oracle."""
+    g = golden('g9_threefield')
+    N, nb = 512, 6
+    ens = orc.threefield_ensemble(nb, N)
+    nu0 = ens['nu0'].copy(); bc = ens['bc'].copy()
+    nu0[1] = float(g['N512_nu0']); bc[1] = g['N512_bc']
+    s, _ = make_3f_solver(tango, N, nu0, (bc[:, 0].copy(), bc[:, 1].copy(), bc[:, 2].copy()), ic=ens['u0'], iterationsPerCheck=5)
+    assert s._fused is not None and s.batched
+    s.take_timestep()
+    assert s.converged
+    assert abs(int(s.iterationsPerProfile[1]) - int(g['N512_iters'])) <= 1
+    for lab in ('n', 'pi', 'pe'):
+        assert relerr(s.profiles[lab][1], g[f'N512_{lab}']) < TOL
+    for b in (0, 3, 5):
+        (n, pi, pe), it, err = orc.run_3f(ens['u0'][b], ens['u0'][b], ens['u0'][b], 1e6, ens['dx'], tuple(bc[b]), nu0[b], ens['x'],
+                                          0.3, 0.3, 1e-9, 1000)
+        assert abs(int(s.iterationsPerProfile[b]) - it) <= 1
+        assert relerr(s.profiles['n'][b], n) < TOL and relerr(s.profiles['pi'][b], pi) < TOL and relerr(s.profiles['pe'][b], pe) < TOL
