@@ -372,16 +372,21 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                 const double pp = (i == P - 1) ? wr : ue[i < P - 1 ? i + 1 : 0];
                 const double p = ue[i];
                 const double dpdx = ddx_edge1_point<EXACT>(pm, p, pp, first, last, rc);
-                // flux model (tango/extras/shestakov_nonlinear_diffusion.py:59-60)
-                double flux = -(dpdx * dpdx * dpdx) / (p * p);
-                double gx = 1.0, gr = 1.0;
-                if constexpr (GENERAL) {
-                    flux = external ? fl[i] : flux;
-                    gx = Q.gxx_turb ? Q.gxx_turb[jc] : 1.0;
-                    gr = Q.gradx_turb ? Q.gradx_turb[jc] : 1.0;
+                double D, c;
+                if constexpr (GENERAL || EXACT) {
+                    // flux model (tango/extras/shestakov_nonlinear_diffusion.py:59-60)
+                    double flux = -(dpdx * dpdx * dpdx) / (p * p);
+                    double gx = 1.0, gr = 1.0;
+                    if constexpr (GENERAL) {
+                        flux = external ? fl[i] : flux;
+                        gx = Q.gxx_turb ? Q.gxx_turb[jc] : 1.0;
+                        gr = Q.gradx_turb ? Q.gradx_turb[jc] : 1.0;
+                    }
+                    double DH, cH, thv;
+                    flux_split_point(flux, p, dpdx, gx, gr, th, D, c, DH, cH, thv);
+                } else {
+                    shestakov_split_point(p, dpdx, th, D, c);   // built-in flux, Cartesian: one quotient
                 }
-                double D, c, DH, cH, thv;
-                flux_split_point(flux, p, dpdx, gx, gr, th, D, c, DH, cH, thv);
                 // EWMA of D and c (tango/lodestro_method.py:368-369)
                 const double nD = Q.a_turb * D + omt * (seeded ? DE[i] : D);
                 const double nc = Q.a_turb * c + omt * (seeded ? cE[i] : c);
@@ -507,7 +512,9 @@ int grid_1d(int64_t total, int block) {
     return (int)(g < cap ? (g > 0 ? g : 1) : cap);
 }
 
-template <template <int, class> class Launcher, class... Args>
+// HEAVY: kernels whose per-lane state needs more than the 128 registers a 1024-thread workgroup leaves per lane;
+// they take 4096 < n <= 8192 as 512 lanes x 16 points.
+template <template <int, class> class Launcher, bool HEAVY = false, class... Args>
 int dispatch_group(int64_t nb, int n, hipStream_t s, Args... args) {
     constexpr int P = 8;
     const int lanes = pow2_at_least((n + P - 1) / P);
@@ -518,7 +525,10 @@ int dispatch_group(int64_t nb, int n, hipStream_t s, Args... args) {
     if (lanes == 128) return Launcher<P, BlockGroup<128>>::go(nb, n, s, args...);
     if (lanes == 256) return Launcher<P, BlockGroup<256>>::go(nb, n, s, args...);
     if (lanes == 512) return Launcher<P, BlockGroup<512>>::go(nb, n, s, args...);
-    if (lanes == 1024) return Launcher<P, BlockGroup<1024>>::go(nb, n, s, args...);
+    if (lanes == 1024) {
+        if constexpr (HEAVY) return Launcher<16, BlockGroup<512>>::go(nb, n, s, args...);
+        else return Launcher<P, BlockGroup<1024>>::go(nb, n, s, args...);
+    }
     if (n <= 16384) return Launcher<16, BlockGroup<1024>>::go(nb, n, s, args...);
     return fail(TG_ERR_UNSUPPORTED, "point-fastest solvers support n <= 16384%s");
 }
@@ -712,7 +722,7 @@ int tg_picard_1f_step(const tg_state_1f *st, const tg_params_1f *q, tg_stream st
     if (q->smooth_window > 1) return fail(TG_ERR_UNSUPPORTED, "flux smoothing is not fused; smooth the flux with tg_moving_average and pass it as an external flux%s");
     if (st->err && st->err_stride <= 0) return fail(TG_ERR_ARG, "err_stride must be positive%s");
     if (st->nb == 0) return TG_OK;
-    return dispatch_group<Picard1fLauncher>(st->nb, (int)st->n, S(stream), st, q);
+    return dispatch_group<Picard1fLauncher, true>(st->nb, (int)st->n, S(stream), st, q);
 }
 
 int tg_stream_probe(const double *const in[5], double *const out[4], int64_t count, tg_stream stream) {

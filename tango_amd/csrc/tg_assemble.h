@@ -36,16 +36,9 @@ struct Theta {
         : Dmin(Dmin_), Dmax(Dmax_), thr(thr_), span(Dmax_ - Dmin_) {}
 };
 
-// tango/lodestro_method.py:624-634 (DHat, cHat, D, c) with the default theta rule of :667-676.
-// gxx / gradx are the geometric factors on the turbulence grid (1 in Cartesian geometry).
+// The default theta rule of tango/lodestro_method.py:667-676.
 // NaN compares false everywhere, which leaves theta = 1 exactly as the reference's masks do.
-__device__ __forceinline__ void flux_split_point(double flux, double p, double dpdx, double gxx, double gradx,
-                                                 const Theta &th, double &D, double &c, double &DHat,
-                                                 double &cHat, double &theta) {
-    double dh = -flux / (gxx * dpdx);
-    dh = (dpdx == 0.0) ? 0.0 : dh;
-    DHat = dh;
-    cHat = flux / (gradx * p);
+__device__ __forceinline__ double theta_point(double dh, double dpdx, const Theta &th) {
     const bool small = fabs(dpdx) < th.thr;
     // true division: c = (1-theta)*cHat cancels to ~1e-14 of theta's rounding, so theta must round as the reference's does
     const double mid = (1.0 + (th.Dmax - dh) / th.span) / 2.0;
@@ -53,7 +46,33 @@ __device__ __forceinline__ void flux_split_point(double flux, double p, double d
     tv = (dh < th.Dmin) ? 0.0 : tv;
     tv = (small && dh >= th.Dmin && dh <= th.Dmax) ? mid : tv;
     tv = (small && dh > th.Dmax) ? 0.5 : tv;
+    return tv;
+}
+
+// tango/lodestro_method.py:624-634 (DHat, cHat, D, c).
+// gxx / gradx are the geometric factors on the turbulence grid (1 in Cartesian geometry).
+__device__ __forceinline__ void flux_split_point(double flux, double p, double dpdx, double gxx, double gradx,
+                                                 const Theta &th, double &D, double &c, double &DHat,
+                                                 double &cHat, double &theta) {
+    double dh = -flux / (gxx * dpdx);
+    dh = (dpdx == 0.0) ? 0.0 : dh;
+    DHat = dh;
+    cHat = flux / (gradx * p);
+    const double tv = theta_point(dh, dpdx, th);
     theta = tv;
+    D = tv * dh;
+    c = (1.0 - tv) * cHat;
+}
+
+// The flux -(dp/dx)^3 / p^2 of tango/extras/shestakov_nonlinear_diffusion.py:59-60 pushed through the split above in
+// Cartesian geometry, from the single quotient r = (dp/dx)/p: DHat = -flux/(dp/dx) = r^2 (0 where dp/dx is 0),
+// cHat = flux/p = -r^3.  One division instead of three; DHat and cHat differ from the three-division values by
+// rounding only (a few ulp).
+__device__ __forceinline__ void shestakov_split_point(double p, double dpdx, const Theta &th, double &D, double &c) {
+    const double r = dpdx / p;
+    const double dh = r * r;
+    const double cHat = -(dh * r);
+    const double tv = theta_point(dh, dpdx, th);
     D = tv * dh;
     c = (1.0 - tv) * cHat;
 }

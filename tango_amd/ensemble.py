@@ -39,6 +39,23 @@ def shestakov_ensemble(nb, n, seed=12345, lo=0, hi=None):
     return dict(x=x, dx=dx, u0=u0, nL=nL[sl].copy(), S0=S0[sl].copy(), delta=delta[sl].copy())
 
 
+def threefield_ensemble(nb, n, seed=2024, lo=0, hi=None):
+    """Three-field ensemble around examples/shestakov_threefield_nonlinearnu.py:159-206: collision amplitude nu0
+    in [1, 4] and the right boundary values of (n, pi, pe) within 25 % of (2, 0.1, 0.3), initial profiles
+    1 - 0.5 x for all three fields; member 0 is the example itself (nu0 = 2.2).  Drawn with
+    numpy.random.default_rng(seed) in the order nu0, boundary factors; [lo, hi) selects a shard."""
+    hi = nb if hi is None else hi
+    rng = np.random.default_rng(seed)
+    nu0 = rng.uniform(1.0, 4.0, size=nb)
+    bc = np.array([2.0, 0.1, 0.3])[None, :] * rng.uniform(0.75, 1.25, size=(nb, 3))
+    nu0[0] = 2.2
+    bc[0] = (2.0, 0.1, 0.3)
+    dx = 1.0 / (n - 1)
+    x = np.arange(n) * dx
+    u0 = np.broadcast_to(1 - 0.5 * x, (hi - lo, n)).copy()
+    return dict(x=x, dx=dx, u0=u0, nu0=nu0[lo:hi].copy(), bc=bc[lo:hi].copy())
+
+
 def source_cut(x, delta):
     """Number of grid points with x < delta for every profile (x increasing): the box source S0*[x < delta] of
     tango/extras/shestakov_nonlinear_diffusion.py:63-68 is then S0 for j < cut."""

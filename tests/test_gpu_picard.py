@@ -14,18 +14,26 @@ TOL = 1e-10   # parity bar: fp64 results within 1e-10 relative of the reference
 # residual (~1e-11) is a difference of terms of size ~1e5*u and is itself rounding noise at the 1e-12 level (eps*|B||u|/max|f|).
 
 
-def same_stop(got, ref_iters, ref_err, tol):
+def same_stop(got, ref_iters, ref_err, tol, got_err=None):
     """Stop-iteration parity.  The rms residual that decides convergence carries rounding noise of ~3e-12
     (the exactly-solved system rounded to fp64 already has that residual), a quarter of the examples' tol of
-    1e-11, so a profile whose deciding residual in the reference lies within 25 % of tol may legitimately stop
-    one iteration earlier or later; every other profile must stop on the reference's iteration."""
+    1e-11, so a residual within 25 % of tol may fall on either side of it.  A profile may stop earlier than in
+    the reference only if the reference's residuals from that iteration on were all within 25 % above tol
+    (it hovered just above tol until it happened to dip below), and later only if the reference's deciding
+    residual was within 25 % below tol and, when the residual history of the run under test is given, its own
+    residuals stayed within 25 % above tol until it stopped.  Every other profile must stop on the reference's
+    iteration.  (A few members of the seeded ensembles have a residual floor of ~1.1e-11: the reference itself
+    stops on them after anything from 70 to more than 400 iterations.)"""
     if got == ref_iters:
         return True
-    if got == ref_iters + 1:
-        return ref_err[ref_iters - 1] > 0.75 * tol
-    if got == ref_iters - 1:
-        return ref_err[ref_iters - 2] < 1.25 * tol
-    return False
+    if got > ref_iters:
+        ok = ref_err[ref_iters - 1] > 0.75 * tol
+        if got_err is not None:
+            ok = ok and bool(np.all(np.asarray(got_err[ref_iters - 1:got - 1]) < 1.25 * tol))
+        else:
+            ok = ok and got == ref_iters + 1
+        return bool(ok)
+    return bool(np.all(np.asarray(ref_err[got - 1:ref_iters - 1]) < 1.25 * tol))
 
 
 @pytest.fixture(scope='module')
@@ -139,7 +147,7 @@ def test_ensemble32_matches_reference(tango, golden):
     same = 0
     for b in range(32):
         got, k = int(s.iterationsPerProfile[b]), int(g['iters'][b])
-        assert same_stop(got, k, g['errs'][b], 1e-11), b
+        assert same_stop(got, k, g['errs'][b], 1e-11, s.errHistory[b]), b
         same += got == k
         k2 = min(got, k)
         assert np.allclose(s.errHistory[b, :k2], g['errs'][b, :k2], rtol=1e-6, atol=2e-12)
