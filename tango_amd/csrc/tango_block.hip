@@ -154,6 +154,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     const bool lane_first = (t == 0);
     const Theta th(Q.Dmin, Q.Dmax, Q.dpdx_thr);
     const double omp = 1.0 - Q.a_prof, omt = 1.0 - Q.a_turb;
+    // grids of more than 512 points keep the reference's divisions (see tg_assemble.h)
+    constexpr bool EXACT = (G::T * P > 512);
 
     double u[3][P + 2], DE[3][P], cE[3][P];
 #pragma unroll
@@ -191,16 +193,32 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             const bool first = (j == 0), last = (j == n - 1);
             double dd[3];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) dd[s] = ddx_edge1_point<true>(ue[s][i], ue[s][i + 1], ue[s][i + 2], first, last, rc);
+            for (int s = 0; s < 3; ++s) dd[s] = ddx_edge1_point<EXACT>(ue[s][i], ue[s][i + 1], ue[s][i + 2], first, last, rc);
             const double pi = ue[1][i + 1];
-            const double Dsh = (dd[1] * dd[1]) / (pi * pi);     // D = (dpi/dx)^2 / pi^2, shared by the three fluxes
+            if constexpr (EXACT) {
+                const double Dsh = (dd[1] * dd[1]) / (pi * pi);     // D = (dpi/dx)^2 / pi^2, shared by the three fluxes
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const double flux = -Dsh * dd[s];
-                double D, c, DH, cH, thv;
-                flux_split_point(flux, ue[s][i + 1], dd[s], 1.0, 1.0, th, D, c, DH, cH, thv);
-                DE[s][i] = Q.a_turb * D + omt * (seeded ? DE[s][i] : D);
-                cE[s][i] = Q.a_turb * c + omt * (seeded ? cE[s][i] : c);
+                for (int s = 0; s < 3; ++s) {
+                    const double flux = -Dsh * dd[s];
+                    double D, c, DH, cH, thv;
+                    flux_split_point(flux, ue[s][i + 1], dd[s], 1.0, 1.0, th, D, c, DH, cH, thv);
+                    DE[s][i] = Q.a_turb * D + omt * (seeded ? DE[s][i] : D);
+                    cE[s][i] = Q.a_turb * c + omt * (seeded ? cE[s][i] : c);
+                }
+            } else {
+                // the same through the quotient r = (dpi/dx)/pi: DHat = -flux/(du/dx) = r^2 for every field (0 where
+                // du/dx is 0), cHat = flux/u = -r^2 (du/dx)/u, which for pi itself is -r^3
+                const double r = dd[1] / pi;
+                const double Dsh = r * r;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const double dh = (dd[s] == 0.0) ? 0.0 : Dsh;
+                    const double cHat = (s == 1) ? -(Dsh * r) : -(Dsh * dd[s]) / ue[s][i + 1];
+                    double D, c;
+                    split_from_hats(dh, cHat, dd[s], th, D, c);
+                    DE[s][i] = Q.a_turb * D + omt * (seeded ? DE[s][i] : D);
+                    cE[s][i] = Q.a_turb * c + omt * (seeded ? cE[s][i] : c);
+                }
             }
         }
 #pragma unroll
@@ -278,7 +296,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             const double hp3 = (h3c[s] + h3n) / 2.0;
             const double bp = fbeta_point(hp2, hp3, rc.dx);
             const double h6 = (s == 0) ? 0.0 : -nu;       // H6 = -nu for pi and pe (example :125, :144)
-            fd_row<true>(last, 1.0, um1[s][i], rc, UL[s], hm2[s], hm3[s], bm[s], hp2, hp3, bp, 0.0, h6, Q.H7[s][jc], A[s], B[s],
+            fd_row<EXACT>(last, 1.0, um1[s][i], rc, UL[s], hm2[s], hm3[s], bm[s], hp2, hp3, bp, 0.0, h6, Q.H7[s][jc], A[s], B[s],
                          C[s], f[s]);
             if (!valid) {
                 A[s] = 0.0; B[s] = 1.0; C[s] = 0.0; f[s] = 0.0;

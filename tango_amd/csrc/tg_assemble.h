@@ -64,6 +64,13 @@ __device__ __forceinline__ void flux_split_point(double flux, double p, double d
     c = (1.0 - tv) * cHat;
 }
 
+// D = theta DHat, c = (1 - theta) cHat (tango/lodestro_method.py:631-634) from DHat and cHat formed by the caller
+__device__ __forceinline__ void split_from_hats(double dh, double cHat, double dpdx, const Theta &th, double &D, double &c) {
+    const double tv = theta_point(dh, dpdx, th);
+    D = tv * dh;
+    c = (1.0 - tv) * cHat;
+}
+
 // The flux -(dp/dx)^3 / p^2 of tango/extras/shestakov_nonlinear_diffusion.py:59-60 pushed through the split above in
 // Cartesian geometry, from the single quotient r = (dp/dx)/p: DHat = -flux/(dp/dx) = r^2 (0 where dp/dx is 0),
 // cHat = flux/p = -r^3.  One division instead of three; DHat and cHat differ from the three-division values by
@@ -71,10 +78,7 @@ __device__ __forceinline__ void flux_split_point(double flux, double p, double d
 __device__ __forceinline__ void shestakov_split_point(double p, double dpdx, const Theta &th, double &D, double &c) {
     const double r = dpdx / p;
     const double dh = r * r;
-    const double cHat = -(dh * r);
-    const double tv = theta_point(dh, dpdx, th);
-    D = tv * dh;
-    c = (1.0 - tv) * cHat;
+    split_from_hats(dh, -(dh * r), dpdx, th, D, c);
 }
 
 // tango/HToMatrixFD.py:277-297: adaptive upwinding weight at a half-integer grid point.
