@@ -38,7 +38,8 @@ enum {
     TG_ST_CONVERGED = 1, /* residual dropped below tol (tango/solver.py:472-475) */
     TG_ST_INVALID = 2,   /* NaN, Inf or negative value in a new profile (tango/solver.py:420-439) */
     TG_ST_SINGULAR = 4,  /* zero pivot met (scipy raises LinAlgError on it) */
-    TG_ST_SEEDED = 8     /* the EWMA memories hold a previous iterate (tango/lodestro_method.py:706-708) */
+    TG_ST_SEEDED = 8,    /* the EWMA memories hold a previous iterate (tango/lodestro_method.py:706-708) */
+    TG_ST_TREAD_LIMIT = 16 /* pseudo-timestep control gave up halving after TG_TREAD_MAX_HALVINGS (see tg_params_1f) */
 };
 
 /* ---- library / device / memory plumbing (no reference counterpart) ------------------------- */
@@ -168,8 +169,22 @@ typedef struct {
     int32_t frozen_turb;   /* nonzero: reuse DE,cE as they are (inner iteration, tango/solver.py:274-309) */
     int32_t iters_per_launch; /* <= 1: one iteration per call; k > 1: up to k iterations per call with the profile
                                  held in registers in between (each profile still stops on its own iteration) */
+    /* Pseudo-timestep control (tango/solver.py:198-216,233-235,311-372).  pseudo_time: the previous iterate takes
+     * the u_{m-1} slot every iteration (useTreadLightly or useTreadInitially).  tread_initial_steps > 0: the first
+     * that many iterations of a profile use tread_initial_dtau instead of dt.  tread_lightly: a new iterate whose
+     * first tread_inner_count = int(innerFraction*n) points changed by a fraction >= tread_max_change is redone from
+     * the previous iterate with the same D, c and dtau = dt/2, dt/4, ... until acceptable (the reference loops
+     * without bound; here a profile stops after TG_TREAD_MAX_HALVINGS and gets TG_ST_TREAD_LIMIT). */
+    int32_t pseudo_time;
+    int32_t tread_lightly;
+    int32_t tread_inner_count;
+    int32_t tread_initial_steps;
     int32_t reserved_;
+    double tread_max_change;
+    double tread_initial_dtau;
 } tg_params_1f;
+
+enum { TG_TREAD_MAX_HALVINGS = 64 };
 
 int tg_picard_1f_step(const tg_state_1f *state, const tg_params_1f *params, tg_stream stream);
 

@@ -568,6 +568,62 @@ def picard_step_1f(st, dt, dx, UL, H1, H7, a_turb, a_prof, theta=THETA_DEFAULT, 
     return rms, profiles_invalid([st.u])
 
 
+def is_unacceptable(old, new, max_fractional_change=0.2, inner_fraction=0.5):
+    """tango/solver.py:564-595: any point of the inner part of the profile changed by the given fraction or more."""
+    k = int(inner_fraction * len(old))
+    with np.errstate(divide='ignore', invalid='ignore'):
+        frac = (new[:k] - old[:k]) / old[:k]
+    return bool(np.any(np.abs(frac) >= max_fractional_change))
+
+
+def picard_step_1f_tread(st, it, dt, dx, UL, H1, H7, a_turb, a_prof, theta=THETA_DEFAULT, tread_lightly=None,
+                         tread_initially=None, solve=tridiag_solve):
+    """One iteration with the pseudo-timestep controls of tango/solver.py:198-235,311-372 for one profile (1-D
+    arrays).  tread_lightly: dict with optional maxFractionalChange / innerFraction, or None;
+    tread_initially: dict with numInitialSteps and dtau, or None.  The previous iterate takes the u_{m-1} slot;
+    an unacceptable step is redone from the previous iterate with the same transport coefficients and
+    dtau = dt/2, dt/4, ... until acceptable.  Returns (rms residual, invalid flag, number of halvings)."""
+    st.um1 = st.u
+    dtau = dt
+    if tread_initially is not None and it < tread_initially['numInitialSteps']:
+        dtau = tread_initially['dtau']
+    H2, H3, _ = turb_coeffs_1f(st, dx, a_turb, a_prof, theta)
+    A, B, C, f = h_to_matrix(dtau, dx, UL, st.um1, H1, H2=H2, H3=H3, H7=H7)
+    rms = rms_of([residual(A, B, C, f, st.u)])
+    old = st.u
+    new = solve(A, B, C, f)
+    halvings = 0
+    if tread_lightly is not None:
+        kw = dict(max_fractional_change=tread_lightly.get('maxFractionalChange', 0.2),
+                  inner_fraction=tread_lightly.get('innerFraction', 0.5))
+        dtau = dt
+        while is_unacceptable(old, new, **kw):
+            dtau /= 2
+            halvings += 1
+            A, B, C, f = h_to_matrix(dtau, dx, UL, old, H1, H2=H2, H3=H3, H7=H7)
+            new = solve(A, B, C, f)
+    st.u = new
+    return rms, profiles_invalid([st.u]), halvings
+
+
+def run_1f_tread(u0, dt, dx, UL, H1, H7, a_turb, a_prof, tol, max_iter, tread_lightly=None, tread_initially=None,
+                 theta=THETA_DEFAULT, solve=tridiag_solve):
+    """One timestep of one profile with pseudo-timestep control; returns (profile, iterations, errHistory,
+    all iterates (iterations, N), halvings per iteration)."""
+    st = State1F(np.asarray(u0, dtype=float))
+    err, hist, halv = [], [], []
+    it = 0
+    done = bad = False
+    while it < max_iter and not done and not bad:
+        rms, bad, h = picard_step_1f_tread(st, it, dt, dx, UL, H1, H7, a_turb, a_prof, theta, tread_lightly,
+                                           tread_initially, solve)
+        err.append(rms); hist.append(st.u.copy()); halv.append(h)
+        done = bool(rms < tol)
+        bad = bool(bad)
+        it += 1
+    return st.u, it, np.array(err), np.array(hist), np.array(halv)
+
+
 def run_1f(u0, dt, dx, UL, H1, H7, a_turb, a_prof, tol, max_iter, theta=THETA_DEFAULT,
            flux_fn=None, smooth_window=1, solve=tridiag_solve, fixed_count=False):
     """One timestep of the reference Solver loop for an ensemble of independent one-field

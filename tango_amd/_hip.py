@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('TANGO_HIP_LIB') or os.path.join(_HERE, 'lib', 'libtan
 
 TG_OK, TG_ERR_ARG, TG_ERR_HIP, TG_ERR_UNSUPPORTED = 0, 1, 2, 3
 POINT_FASTEST, BATCH_FASTEST = 0, 1
-ST_CONVERGED, ST_INVALID, ST_SINGULAR, ST_SEEDED = 1, 2, 4, 8
+ST_CONVERGED, ST_INVALID, ST_SINGULAR, ST_SEEDED, ST_TREAD_LIMIT = 1, 2, 4, 8, 16
 FLUX_SHESTAKOV, FLUX_EXTERNAL = 0, 1
 
 
@@ -52,7 +52,9 @@ class Params1F(C.Structure):
                 ('h7_stride', _i64), ('S0', _p), ('src_cut', _p), ('Vprime', _p), ('gxx', _p),
                 ('gradx', _p), ('gxx_turb', _p), ('gradx_turb', _p), ('flux', _p), ('flux_model', C.c_int32),
                 ('smooth_window', C.c_int32), ('fixed_count', C.c_int32), ('frozen_turb', C.c_int32),
-                ('iters_per_launch', C.c_int32), ('reserved_', C.c_int32)]
+                ('iters_per_launch', C.c_int32), ('pseudo_time', C.c_int32), ('tread_lightly', C.c_int32),
+                ('tread_inner_count', C.c_int32), ('tread_initial_steps', C.c_int32), ('reserved_', C.c_int32),
+                ('tread_max_change', _dbl), ('tread_initial_dtau', _dbl)]
 
 
 class State3F(C.Structure):

@@ -318,7 +318,8 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     const int t = g.t();
     const int j0 = t * P;
     const int64_t off = b * S_.n;
-    const Recip rc(Q.dx, Q.dt_b ? Q.dt_b[b] : Q.dt);
+    const double dt_full = Q.dt_b ? Q.dt_b[b] : Q.dt;
+    Recip rc(Q.dx, dt_full);
     const double UL = Q.UL[b];
     const bool lane_first = (t == 0);
     // grids beyond one wavefront (n > 512) have condition numbers above 1e9: keep the reference's divisions
@@ -351,6 +352,15 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         // A group that is done keeps executing (other groups of the wavefront may not be) but every update of
         // its state below is a select on `done`, so nothing of it changes any more.
         const bool seeded = (st & TG_ST_SEEDED) != 0;
+        if constexpr (GENERAL) {
+            if (Q.pseudo_time) {
+                // the previous iterate takes the u_{m-1} slot (tango/solver.py:198-201); treadInitially's short
+                // pseudo-timestep for a profile's first iterations (:210-215)
+#pragma unroll
+                for (int i = 0; i < P; ++i) um1[i] = done ? um1[i] : u[i + 1];
+                rc = Recip(Q.dx, (it0 < Q.tread_initial_steps) ? Q.tread_initial_dtau : dt_full);
+            }
+        }
         if (!Q.frozen_turb) {
             // EWMA of the profile (tango/lodestro_method.py:345); with an external flux the caller has advanced it
             if (!external) {
@@ -424,6 +434,16 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
 
         // Assemble row by row and eliminate at once.  Half-grid slot "m" lies between local points i-1 and i,
         // slot "p" between i and i+1; the p values of row i are the m values of row i+1.
+        // With tread_lightly the assembly and solve are repeated with halved pseudo-timesteps until the step is
+        // acceptable (tango/solver.py:361-371); `settled` marks the profiles that have their new iterate.
+        double x[P];
+        double rms = 0.0;
+        int singular = 0;
+        bool settled = done;
+        bool tread_limit = false;
+        double dtau = dt_full;
+#pragma unroll 1
+        for (int attempt = 0;; ++attempt) {
         ChunkElim<P> el;
         double hm2 = lane_first ? 0.0 : (h2l + h2first) / 2.0;
         double hm3 = lane_first ? 0.0 : (h3l + h3first) / 2.0;
@@ -462,20 +482,47 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             h2c = h2n;
             h3c = h3n;
         }
-        // rms of r / max|f| (tango/fieldgroups.py:140, tango/solver.py:464-470)
-        mx = g.max(mx);
-        ss = g.sum(ss);
-        const double rms = sqrt(1.0 / (double)n * (ss / (mx * mx)));
+        // rms of r / max|f| (tango/fieldgroups.py:140, tango/solver.py:464-470): the first solve's matrix decides
+        if (attempt == 0) {
+            mx = g.max(mx);
+            ss = g.sum(ss);
+            rms = sqrt(1.0 / (double)n * (ss / (mx * mx)));
+        }
 
-        double x[P];
-        el.finish(g, x);
+        double xt[P];
+        el.finish(g, xt);
+        if constexpr (!GENERAL) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) x[i] = xt[i];
+            singular = el.singular;
+            break;
+        } else {
+#pragma unroll
+            for (int i = 0; i < P; ++i) x[i] = settled ? x[i] : xt[i];
+            singular |= settled ? 0 : el.singular;
+            if (!Q.tread_lightly) break;
+            // tango/solver.py:564-595: a change of maxFractionalChange or more anywhere in the inner part
+            int far = 0;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const double change = (xt[i] - u[i + 1]) / u[i + 1];
+                far |= (j0 + i < Q.tread_inner_count) && (fabs(change) >= Q.tread_max_change);
+            }
+            far = g.any(far);
+            if (!settled && far && attempt >= TG_TREAD_MAX_HALVINGS) tread_limit = true;
+            settled = settled || !far || attempt >= TG_TREAD_MAX_HALVINGS;
+            if (G::kBlock ? settled : !__any(!settled)) break;
+            dtau = settled ? dtau : dtau / 2.0;
+            rc = Recip(Q.dx, dtau);
+        }
+        }   // attempts
         int bad = 0;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             bad |= (FULL || j0 + i < n) ? !(isfinite(x[i]) && x[i] >= 0.0) : 0;
             u[i + 1] = done ? u[i + 1] : x[i];
         }
-        bad = g.any(bad | (el.singular << 1));
+        bad = g.any(bad | (singular << 1));
 
         if (!done) {
             if (t == 0 && S_.err && it0 < S_.err_stride) S_.err[b * S_.err_stride + it0] = rms;
@@ -484,6 +531,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             if (!Q.fixed_count && rms < Q.tol) st |= TG_ST_CONVERGED;
             if (bad & 1) st |= TG_ST_INVALID;
             if (bad & 2) st |= TG_ST_SINGULAR;
+            if (tread_limit) st |= TG_ST_TREAD_LIMIT;
             done = !Q.fixed_count && (st & (TG_ST_CONVERGED | TG_ST_INVALID));
         }
         // leave when every profile handled by this wavefront (workgroup) is done
@@ -559,7 +607,7 @@ struct Picard1fLauncher {
                        reinterpret_cast<uintptr_t>(st->uE) | reinterpret_cast<uintptr_t>(st->DE) |
                        reinterpret_cast<uintptr_t>(st->cE) | reinterpret_cast<uintptr_t>(q->flux);
         const bool full = (n == P * G::T) && (al & 15) == 0;
-        const bool general = q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb;
+        const bool general = q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly;
         const bool multi = q->iters_per_launch > 1;
 #define TG_LAUNCH_1F(F, GEN, M) hipLaunchKernelGGL((picard_1f_kernel<P, G, F, GEN, M>), dim3(grid), dim3(block), lds, s, *st, *q)
         if (general) {
@@ -719,6 +767,11 @@ int tg_picard_1f_step(const tg_state_1f *st, const tg_params_1f *q, tg_stream st
     if (q->flux_model == TG_FLUX_EXTERNAL && !q->flux) return fail(TG_ERR_ARG, "external flux model needs a flux array%s");
     if (q->flux_model != TG_FLUX_EXTERNAL && q->flux_model != TG_FLUX_SHESTAKOV) return fail(TG_ERR_ARG, "unknown flux model%s");
     if (q->flux_model == TG_FLUX_EXTERNAL && q->iters_per_launch > 1) return fail(TG_ERR_ARG, "an external flux is valid for one iteration only%s");
+    if (q->tread_lightly && !q->pseudo_time) return fail(TG_ERR_ARG, "tread_lightly needs pseudo_time (the previous iterate in the u_{m-1} slot)%s");
+    if (q->tread_lightly && (q->tread_inner_count < 0 || q->tread_inner_count > st->n || !(q->tread_max_change > 0.0)))
+        return fail(TG_ERR_ARG, "tread_lightly needs 0 <= tread_inner_count <= n and tread_max_change > 0%s");
+    if (q->tread_initial_steps < 0 || (q->tread_initial_steps > 0 && (!q->pseudo_time || !(q->tread_initial_dtau > 0.0))))
+        return fail(TG_ERR_ARG, "tread_initial_steps needs pseudo_time and tread_initial_dtau > 0%s");
     if (q->smooth_window > 1) return fail(TG_ERR_UNSUPPORTED, "flux smoothing is not fused; smooth the flux with tg_moving_average and pass it as an external flux%s");
     if (st->err && st->err_stride <= 0) return fail(TG_ERR_ARG, "err_stride must be positive%s");
     if (st->nb == 0) return TG_OK;

@@ -372,8 +372,11 @@ def is_unacceptable_one_profile(oldProfile, newProfile, maxFractionalChange=0.2,
 # ---------------------------------------------------------------------- fused path
 def _plan_fused(s):
     """Return a fused-path runner when the problem is one the fused kernels implement, else None."""
-    if (s.user_control_func is not None or s.useTreadLightly or s.useTreadInitially
-            or s.saveFluxesInMemory or s.maxIterationsPerSet != np.inf):
+    if s.user_control_func is not None or s.saveFluxesInMemory or s.maxIterationsPerSet != np.inf:
+        return None
+    if s.useTreadLightly and s.is_unacceptable_one_profile is not is_unacceptable_one_profile:
+        return None      # a user-supplied acceptance test runs on the host
+    if s.useTreadInitially and s.iterationNumber != 0:
         return None
     call = s.compute_all_H_all_fields
     if not isinstance(call, _mf.ComputeAllHAllFields) or type(call.turbhandler) is not _lm.TurbulenceHandler:
@@ -393,6 +396,8 @@ def _plan_fused(s):
             and getattr(s.fields[0].compute_all_H, 'fused_source', None) is not None \
             and th.dxTurbGrid == s.dx and th.fluxModel.dx == s.dx:
         return _Fused1F(s)
+    if s.useTreadLightly or s.useTreadInitially:
+        return None      # pseudo-timestep control is built into the one-field kernel only
     if model == 'threefield_nonlinear_nu' and len(s.fields) == 3:
         from .extras import threefield
         return threefield.plan(s)
@@ -440,6 +445,15 @@ class _Fused1F(object):
         q.Dmin, q.Dmax, q.dpdx_thr, q.tol = float(tp['Dmin']), float(tp['Dmax']), float(tp['dpdxThreshold']), float(s.tol)
         q.UL, q.S0, q.src_cut = self.UL.ptr, self.S0.ptr, self.src_cut.ptr
         q.flux_model, q.smooth_window, q.fixed_count, q.frozen_turb = H.FLUX_SHESTAKOV, 1, 0, 0
+        # pseudo-timestep control (tango/solver.py:198-216, 311-372) runs inside the kernel
+        q.pseudo_time = int(bool(s.useTreadLightly or s.useTreadInitially))
+        if s.useTreadLightly:
+            q.tread_lightly = 1
+            q.tread_max_change = float(s.treadLightlyParams.get('maxFractionalChange', 0.2))
+            q.tread_inner_count = int(s.treadLightlyParams.get('innerFraction', 0.5) * self.n)
+        if s.useTreadInitially:
+            q.tread_initial_steps = int(s.treadInitiallyParams['numInitialSteps'])
+            q.tread_initial_dtau = float(s.treadInitiallyParams['dtau'])
         return q
 
     def run_timestep(self, s):

@@ -203,7 +203,7 @@ class ComputeAllH1F(object):
         return multifield.HCoefficients(H1=H1, H7=H7) + HCoeffsTurb
 
 
-def run_ref_1f(N, nL, S0, delta, n0, a_turb, a_prof, tol, maxit, dt=1e4, keep=()):
+def run_ref_1f(N, nL, S0, delta, n0, a_turb, a_prof, tol, maxit, dt=1e4, keep=(), **solver_kw):
     dx = 1 / (N - 1); x = np.arange(N) * dx
     th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
     fm = shest.AnalyticFluxModel(dx)
@@ -214,7 +214,7 @@ def run_ref_1f(N, nL, S0, delta, n0, a_turb, a_prof, tol, maxit, dt=1e4, keep=()
     fields = [f0]
     multifield.check_fields_initialize(fields)
     call = multifield.ComputeAllHAllFields(fields, turb)
-    s = tsolver.Solver(1, x, np.array([0, dt]), maxit, tol, call, fields)
+    s = tsolver.Solver(1, x, np.array([0, dt]), maxit, tol, call, fields, **solver_kw)
     snaps = {}
     k = 0
     # drive the reference's own loop one iteration at a time so that EWMA states can be recorded
@@ -269,6 +269,28 @@ def g10():
         assert conv and k <= 100
         finals[b] = u; iters[b] = k; errs[b, :k] = err
     save('g10_ensemble32', nL=nL, S0=S0, delta=delta, a=a, s=s, finals=finals, iters=iters, errs=errs)
+
+
+def g12():
+    """Pseudo-timestep control (examples/shestakov_treadlightly.py, shestakov_treadinitially.py of the reference):
+    nL = 1, n0 = -0.2 (x - 1) + 1.2, EWMA 0.1/1, tol 1e-10; every profile iterate is kept."""
+    N = 500
+    x = np.arange(N) * (1 / (N - 1))
+    n0 = -0.2 * (x - 1) + 1.2
+    out = dict(N=N, nL=1.0, n0=n0)
+    cases = {'lightly': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.2}),
+             'lightly_tight': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.05, 'innerFraction': 0.8}),
+             'initially': dict(useTreadInitially=True, treadInitiallyParams={'numInitialSteps': 6, 'dtau': 0.3}),
+             'both': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.1},
+                          useTreadInitially=True, treadInitiallyParams={'numInitialSteps': 4, 'dtau': 0.5})}
+    for tag, kw in cases.items():
+        keep = tuple(range(0, 40))
+        u, k, err, snaps, last, conv = run_ref_1f(N, 1.0, 1.0, 0.1, n0, 0.1, 1.0, 1e-10, 1000, keep=keep, **kw)
+        out.update({f'{tag}_iters': k, f'{tag}_err': err, f'{tag}_final': u, f'{tag}_conv': conv,
+                    f'{tag}_first40': np.stack([snaps[i][0] for i in sorted(snaps)]),
+                    f'{tag}_last_DE': last[1], f'{tag}_last_cE': last[2]})
+        print(tag, 'iterations', k, 'converged', conv)
+    save('g12_tread', **out)
 
 
 # ---------------------------------------------------------------- G9 three-field trajectories
@@ -362,6 +384,6 @@ def g11():
 
 
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11']
+    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12']
     for w in which:
         globals()[w]()

@@ -249,3 +249,63 @@ def test_multi_iteration_launch_equals_single_launches(tango, N, nb):
         for x, y in ((A.u, B.u), (A.uE, B.uE), (A.DE, B.DE), (A.cE, B.cE)):
             assert relerr(y.to_host(), x.to_host()) < 1e-13
         assert np.allclose(A.err.to_host(), B.err.to_host(), rtol=1e-9, atol=1e-15)
+
+
+TREAD_CASES = {'lightly': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.2}),
+               'lightly_tight': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.05, 'innerFraction': 0.8}),
+               'initially': dict(useTreadInitially=True, treadInitiallyParams={'numInitialSteps': 6, 'dtau': 0.3}),
+               'both': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.1},
+                            useTreadInitially=True, treadInitiallyParams={'numInitialSteps': 4, 'dtau': 0.5})}
+
+
+@pytest.mark.parametrize('tag', sorted(TREAD_CASES))
+@pytest.mark.parametrize('fused', [True, False])
+def test_pseudo_timestep_control(tango, golden, tag, fused):
+    """examples/shestakov_treadlightly.py and shestakov_treadinitially.py of the reference: the halving loop runs
+    inside the fused kernel (fused) or on the host around the standalone kernels (generic path)."""
+    g = golden('g12_tread')
+    if not fused and tag not in ('lightly', 'both'):
+        pytest.skip('generic path: two cases are enough')
+    N = int(g['N'])
+    s, lm = make_solver(tango, N, 1.0, 1.0, 0.1, g['n0'], 0.1, 1.0, 1e-10, 1000, fused=fused, saveProfileHistory=True,
+                        **TREAD_CASES[tag])
+    assert (s._fused is not None) == fused
+    while s.ok:
+        s.take_timestep()
+    assert s.reachedEnd and s.converged and not s.solutionError
+    k = int(g[f'{tag}_iters'])
+    assert same_stop(len(s.errHistoryFinal), k, g[f'{tag}_err'], 1e-10, s.errHistoryFinal)
+    m = min(k, len(s.errHistoryFinal))
+    # rounding floor of the rms residual on this problem: eps |B| |u| / max|f| ~ 1e-16 * 1.4e4 * 1.2 / 1 ~ 2e-12 per point
+    assert np.allclose(s.errHistoryFinal[:m], g[f'{tag}_err'][:m], rtol=1e-6, atol=6e-12)
+    assert relerr(s.profilesAllIterations['n'][:40], g[f'{tag}_first40']) < TOL
+    assert relerr(s.profiles['n'], g[f'{tag}_final']) < TOL
+    assert relerr(lm._EWMATurbD._yEWMA_lminus1, g[f'{tag}_last_DE']) < TOL
+
+
+def test_pseudo_timestep_control_ensemble(tango, golden):
+    """Profiles of one launch need different numbers of halvings: members with different acceptance thresholds
+    cannot be mixed in one Solver, so mix initial profiles instead and check every member against the CPU oracle.
+    (An exactly flat initial profile is left out on purpose: its front advances through a region where D is 0 and
+    theta switches discontinuously at DHat = Dmin, so its trajectory amplifies rounding differences to 1e-9 within
+    60 iterations in any implementation.)"""
+    from oracle import tango_oracle as orc
+    N = 256
+    x = np.arange(N) * (1 / (N - 1)); dx = 1 / (N - 1)
+    ics = np.stack([-0.2 * (x - 1) + 1.2, 1.0 + 0.05 * x, 1.5 - 0.5 * x, 1.0 + 0.3 * np.cos(3 * x), 2.0 - x, 1.05 - 0.05 * x])
+    iters = 60          # a fixed number of iterations (tol is unreachable): every member is compared on the same iterate
+    s, lm = make_solver(tango, N, 1.0, 1.0, 0.1, ics, 0.1, 1.0, 1e-30, iters, useTreadLightly=True,
+                        treadLightlyParams={'maxFractionalChange': 0.15}, iterationsPerCheck=4)
+    assert s._fused is not None and s.batched
+    s.take_timestep()
+    assert not s.converged and not s.solutionError and np.all(s.iterationsPerProfile == iters)
+    assert not np.any(s.profileStatus & 16)        # nobody ran into the halving limit
+    H7 = orc.shestakov_source(x, 1.0, 0.1)
+    halvings = []
+    for b in range(len(ics)):
+        u, it, err, hist, halv = orc.run_1f_tread(ics[b], 1e4, dx, 1.0, np.ones(N), H7, 0.1, 1.0, 1e-30, iters,
+                                                  dict(maxFractionalChange=0.15), None)
+        halvings.append(int(halv.sum()))
+        assert np.allclose(s.errHistory[b, :iters], err, rtol=1e-6, atol=6e-12), b
+        assert relerr(s.profiles['n'][b], u) < TOL, b
+    assert len(set(halvings)) > 2 and max(halvings) > 10     # the members really took different paths

@@ -224,3 +224,21 @@ def test_steady_state_integration():
     nss = orc.shestakov_steady_state(x, 1e-2)
     r = (out[0] - nss) / np.max(np.abs(nss))
     assert np.sqrt(np.mean(r ** 2)) < 1e-3
+
+
+def test_g12_pseudo_timestep_control(golden):
+    """tread_lightly / tread_initially (tango/solver.py:198-235,311-372) on the examples' problem."""
+    g = golden('g12_tread')
+    N = int(g['N']); dx = 1 / (N - 1); x = np.arange(N) * dx
+    H7 = orc.shestakov_source(x, 1, 0.1)
+    cases = {'lightly': (dict(maxFractionalChange=0.2), None),
+             'lightly_tight': (dict(maxFractionalChange=0.05, innerFraction=0.8), None),
+             'initially': (None, dict(numInitialSteps=6, dtau=0.3)),
+             'both': (dict(maxFractionalChange=0.1), dict(numInitialSteps=4, dtau=0.5))}
+    for tag, (tl, ti) in cases.items():
+        u, it, err, hist, halv = orc.run_1f_tread(g['n0'], 1e4, dx, 1.0, np.ones(N), H7, 0.1, 1.0, 1e-10, 1000, tl, ti)
+        assert it == int(g[f'{tag}_iters'])
+        assert relerr(u, g[f'{tag}_final']) < 1e-13
+        assert relerr(hist[:40], g[f'{tag}_first40']) < 1e-13
+        assert np.allclose(err, g[f'{tag}_err'], rtol=1e-9, atol=1e-15)
+        assert (halv.sum() > 0) == (tl is not None)
