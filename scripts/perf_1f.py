@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if os.environ.get('TG_LIB'):
     import tango_amd._hip as _h0  # noqa
 from tango_amd import _hip as H
-from oracle import tango_oracle as orc
+from tango_amd import ensemble as orc
 C = H.C
 
 def main(nb=65536, n=512, iters=30, warm=5, a_prof=1.0, kper=1):

@@ -9,6 +9,7 @@
 // last store: the forward-sweep intermediates of the tridiagonal solve never touch memory.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -256,16 +257,21 @@ residual_kernel(const double *__restrict__ A, const double *__restrict__ B, cons
 // for the step's traffic on the device at hand.
 __global__ void __launch_bounds__(256)
 stream_probe_kernel(const double2 *__restrict__ a, const double2 *__restrict__ b, const double2 *__restrict__ c,
-                    const double2 *__restrict__ d, const double2 *__restrict__ e, double2 *__restrict__ w,
-                    double2 *__restrict__ x, double2 *__restrict__ y, double2 *__restrict__ z, int64_t n2) {
+                       const double2 *__restrict__ d, const double2 *__restrict__ e, double2 *__restrict__ w,
+                       double2 *__restrict__ x, double2 *__restrict__ y, double2 *__restrict__ z, int64_t n2) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n2; i += stride) {
-        const double2 va = a[i], vb = b[i], vc = c[i], vd = d[i], ve = e[i];
-        w[i] = make_double2(va.x + vb.x, va.y + vb.y);
-        x[i] = make_double2(vb.x + vc.x, vb.y + vc.y);
-        y[i] = make_double2(vc.x + vd.x, vc.y + vd.y);
-        z[i] = make_double2(vd.x + ve.x, vd.y + ve.y);
+        double2 va, vb, vc, vd, ve;
+        va.x = __builtin_nontemporal_load(&a[i].x); va.y = __builtin_nontemporal_load(&a[i].y);
+        vb.x = __builtin_nontemporal_load(&b[i].x); vb.y = __builtin_nontemporal_load(&b[i].y);
+        vc.x = __builtin_nontemporal_load(&c[i].x); vc.y = __builtin_nontemporal_load(&c[i].y);
+        vd.x = __builtin_nontemporal_load(&d[i].x); vd.y = __builtin_nontemporal_load(&d[i].y);
+        ve.x = __builtin_nontemporal_load(&e[i].x); ve.y = __builtin_nontemporal_load(&e[i].y);
+        __builtin_nontemporal_store(va.x + vb.x, &w[i].x); __builtin_nontemporal_store(va.y + vb.y, &w[i].y);
+        __builtin_nontemporal_store(vb.x + vc.x, &x[i].x); __builtin_nontemporal_store(vb.y + vc.y, &x[i].y);
+        __builtin_nontemporal_store(vc.x + vd.x, &y[i].x); __builtin_nontemporal_store(vc.y + vd.y, &y[i].y);
+        __builtin_nontemporal_store(vd.x + ve.x, &z[i].x); __builtin_nontemporal_store(vd.y + ve.y, &z[i].y);
     }
 }
 
@@ -786,8 +792,8 @@ int tg_stream_probe(const double *const in[5], double *const out[4], int64_t cou
         if (!out[k] || (reinterpret_cast<uintptr_t>(out[k]) & 15)) return fail(TG_ERR_ARG, "outputs must be 16-byte aligned%s");
     if (count == 0) return TG_OK;
     const int64_t n2 = count / 2;
-    int64_t blocks = (n2 + 255) / 256;
-    if (blocks > 256 * 64) blocks = 256 * 64;
+    int64_t blocks = (n2 + 255) / 256;      // one element per thread measures fastest; grid-stride beyond 2^22 blocks
+    if (blocks > (1 << 22)) blocks = 1 << 22;
     hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, S(stream), (const double2 *)in[0],
                        (const double2 *)in[1], (const double2 *)in[2], (const double2 *)in[3], (const double2 *)in[4],
                        (double2 *)out[0], (double2 *)out[1], (double2 *)out[2], (double2 *)out[3], n2);
