@@ -19,6 +19,7 @@
 #include "tg_host.h"
 #include "tg_io.h"
 #include "tg_solve.h"
+#include "tg_wave_io.h"
 
 thread_local char tg_err_buf[512] = "";
 
@@ -311,6 +312,10 @@ __global__ void status_reduce_kernel(const int32_t *__restrict__ status, int64_t
 // GENERAL = false is the Cartesian case with the built-in flux (no geometry arrays, no external flux): H2 and H3
 // are then the EWMA memories themselves and need no registers of their own.
 // MULTI = false compiles the single-iteration form (no loop, no selects on `done`).
+// rows go through the coalesced path of tg_wave_io.h when a wavefront owns exactly one full 512-point profile
+template <int P, class G, bool FULL>
+constexpr bool kWaveCoop = !G::kBlock && G::T == 64 && FULL && P == 8;
+
 template <int P, class G, bool FULL, bool GENERAL, bool MULTI>
 __global__ void __launch_bounds__(G::kBlock ? G::T : 256, G::kBlock ? 1 : 2)   // two wavefronts per SIMD: <= 256 registers
 picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
@@ -342,11 +347,37 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     // the whole state of the profile, loaded once
     double u[P + 2], ue[P], um1[P], DE[P], cE[P];
     double fl[GENERAL ? P : 1];
-    load_chunk<P, FULL>(S_.u + off, n, j0, u + 1, 0.0);
-    load_chunk<P, FULL>(S_.uE + off, n, j0, ue, 1.0);
-    load_chunk<P, FULL>(S_.DE + off, n, j0, DE, 0.0);
-    load_chunk<P, FULL>(S_.cE + off, n, j0, cE, 0.0);
-    load_chunk<P, FULL>(S_.um1 + off, n, j0, um1, 0.0);
+    // one profile per wavefront: rows move coalesced and are transposed through the wavefront's LDS tiles
+    constexpr bool COOP = kWaveCoop<P, G, FULL>;
+    WaveTile wt(lds + (COOP ? (threadIdx.x >> 6) * 4 * kWaveTileDoubles : 0));
+    if constexpr (COOP) {
+        double2 r0[4], r1[4], r2[4], r3[4], r4[4];
+        wt.fetch(S_.u + off, r0);
+        wt.fetch(S_.uE + off, r1);
+        wt.fetch(S_.DE + off, r2);
+        wt.fetch(S_.cE + off, r3);
+        wt.fetch(S_.um1 + off, r4);
+        wt.stage(0, r0);
+        wt.stage(1, r1);
+        wt.stage(2, r2);
+        wt.stage(3, r3);
+        WaveTile::sync();
+        wt.take(0, u + 1);
+        wt.take(1, ue);
+        wt.take(2, DE);
+        wt.take(3, cE);
+        WaveTile::sync();
+        wt.stage(0, r4);
+        WaveTile::sync();
+        wt.take(0, um1);
+        WaveTile::sync();
+    } else {
+        load_chunk<P, FULL>(S_.u + off, n, j0, u + 1, 0.0);
+        load_chunk<P, FULL>(S_.uE + off, n, j0, ue, 1.0);
+        load_chunk<P, FULL>(S_.DE + off, n, j0, DE, 0.0);
+        load_chunk<P, FULL>(S_.cE + off, n, j0, cE, 0.0);
+        load_chunk<P, FULL>(S_.um1 + off, n, j0, um1, 0.0);
+    }
     if constexpr (GENERAL) {
         if (external) load_chunk<P, FULL>(Q.flux + off, n, j0, fl, 0.0);
     }
@@ -545,11 +576,28 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         if (G::kBlock ? done : !__any(!done)) break;
     }
 
-    store_chunk<P, FULL>(S_.u + off, n, j0, u + 1);
-    if (!Q.frozen_turb) {
-        if (!external) store_chunk<P, FULL>(S_.uE + off, n, j0, ue);
-        store_chunk<P, FULL>(S_.DE + off, n, j0, DE);
-        store_chunk<P, FULL>(S_.cE + off, n, j0, cE);
+    if constexpr (COOP) {
+        const bool turb = !Q.frozen_turb;
+        wt.put(0, u + 1);
+        if (turb) {
+            wt.put(1, ue);
+            wt.put(2, DE);
+            wt.put(3, cE);
+        }
+        WaveTile::sync();
+        wt.flush(0, S_.u + off);
+        if (turb) {
+            if (!external) wt.flush(1, S_.uE + off);
+            wt.flush(2, S_.DE + off);
+            wt.flush(3, S_.cE + off);
+        }
+    } else {
+        store_chunk<P, FULL>(S_.u + off, n, j0, u + 1);
+        if (!Q.frozen_turb) {
+            if (!external) store_chunk<P, FULL>(S_.uE + off, n, j0, ue);
+            store_chunk<P, FULL>(S_.DE + off, n, j0, DE);
+            store_chunk<P, FULL>(S_.cE + off, n, j0, cE);
+        }
     }
     if (t == 0) {
         S_.iters[b] = it0;
@@ -615,6 +663,7 @@ struct Picard1fLauncher {
         const bool full = (n == P * G::T) && (al & 15) == 0;
         const bool general = q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly;
         const bool multi = q->iters_per_launch > 1;
+        if (kWaveCoop<P, G, true> && full) lds = (size_t)(block / 64) * 4 * kWaveTileDoubles * sizeof(double);
 #define TG_LAUNCH_1F(F, GEN, M) hipLaunchKernelGGL((picard_1f_kernel<P, G, F, GEN, M>), dim3(grid), dim3(block), lds, s, *st, *q)
         if (general) {
             if (full) TG_LAUNCH_1F(true, true, true);
