@@ -9,6 +9,7 @@
 // last store: the forward-sweep intermediates of the tridiagonal solve never touch memory.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
@@ -312,9 +313,9 @@ __global__ void status_reduce_kernel(const int32_t *__restrict__ status, int64_t
 // GENERAL = false is the Cartesian case with the built-in flux (no geometry arrays, no external flux): H2 and H3
 // are then the EWMA memories themselves and need no registers of their own.
 // MULTI = false compiles the single-iteration form (no loop, no selects on `done`).
-// rows go through the coalesced path of tg_wave_io.h when a wavefront owns exactly one full 512-point profile
+// rows can go through the coalesced path of tg_wave_io.h when a wavefront owns whole profiles, 512 points in all
 template <int P, class G, bool FULL>
-constexpr bool kWaveCoop = !G::kBlock && G::T == 64 && FULL && P == 8;
+constexpr bool kWaveCoop = !G::kBlock && FULL && P == 8;
 
 template <int P, class G, bool FULL, bool GENERAL, bool MULTI>
 __global__ void __launch_bounds__(G::kBlock ? G::T : 256, G::kBlock ? 1 : 2)   // two wavefronts per SIMD: <= 256 registers
@@ -322,9 +323,18 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     extern __shared__ double lds[];
     G g(lds);
     const int64_t b = (int64_t)blockIdx.x * G::profiles_per_block(blockDim.x) + g.profile_in_block();
-    if (b >= S_.nb) return;
+    // Rows move coalesced and are transposed through the wavefront's LDS tiles (tg_wave_io.h) when the wavefront
+    // owns 512 consecutive doubles of every array: always with one profile per wavefront (COOP_ALWAYS), and with
+    // several short profiles per wavefront as long as all of them exist (not the tail of the ensemble).  Profiles
+    // of such a wavefront that need no iteration stay in it as `done` from the start and take part in the I/O.
+    constexpr bool COOP_T = kWaveCoop<P, G, FULL>;
+    constexpr bool COOP_ALWAYS = COOP_T && G::T == 64;
+    const bool exists = b < S_.nb;
+    const bool coop = COOP_ALWAYS || (COOP_T && __all(exists));
+    if (!exists) return;
     int st = S_.status[b];
-    if (!Q.fixed_count && (st & (TG_ST_CONVERGED | TG_ST_INVALID))) return;
+    const bool active = Q.fixed_count || !(st & (TG_ST_CONVERGED | TG_ST_INVALID));
+    if ((COOP_T && !COOP_ALWAYS && coop) ? !__any(active) : !active) return;
     const int n = (int)S_.n;
     const int t = g.t();
     const int j0 = t * P;
@@ -347,16 +357,15 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     // the whole state of the profile, loaded once
     double u[P + 2], ue[P], um1[P], DE[P], cE[P];
     double fl[GENERAL ? P : 1];
-    // one profile per wavefront: rows move coalesced and are transposed through the wavefront's LDS tiles
-    constexpr bool COOP = kWaveCoop<P, G, FULL>;
-    WaveTile wt(lds + (COOP ? (threadIdx.x >> 6) * 4 * kWaveTileDoubles : 0));
-    if constexpr (COOP) {
+    const int64_t woff = off - (int64_t)((threadIdx.x & 63) / G::T) * S_.n;   // first profile of this wavefront
+    WaveTile wt(lds + (COOP_T ? (threadIdx.x >> 6) * 4 * kWaveTileDoubles : 0));
+    auto load_state_coop = [&]() {
         double2 r0[4], r1[4], r2[4], r3[4], r4[4];
-        wt.fetch(S_.u + off, r0);
-        wt.fetch(S_.uE + off, r1);
-        wt.fetch(S_.DE + off, r2);
-        wt.fetch(S_.cE + off, r3);
-        wt.fetch(S_.um1 + off, r4);
+        wt.fetch(S_.u + woff, r0);
+        wt.fetch(S_.uE + woff, r1);
+        wt.fetch(S_.DE + woff, r2);
+        wt.fetch(S_.cE + woff, r3);
+        wt.fetch(S_.um1 + woff, r4);
         wt.stage(0, r0);
         wt.stage(1, r1);
         wt.stage(2, r2);
@@ -371,21 +380,32 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         WaveTile::sync();
         wt.take(0, um1);
         WaveTile::sync();
-    } else {
+    };
+    auto load_state_lane = [&]() {
         load_chunk<P, FULL>(S_.u + off, n, j0, u + 1, 0.0);
         load_chunk<P, FULL>(S_.uE + off, n, j0, ue, 1.0);
         load_chunk<P, FULL>(S_.DE + off, n, j0, DE, 0.0);
         load_chunk<P, FULL>(S_.cE + off, n, j0, cE, 0.0);
         load_chunk<P, FULL>(S_.um1 + off, n, j0, um1, 0.0);
+    };
+    if constexpr (COOP_ALWAYS) {
+        load_state_coop();
+    } else if constexpr (COOP_T) {
+        if (coop) load_state_coop();
+        else load_state_lane();
+    } else {
+        load_state_lane();
     }
     if constexpr (GENERAL) {
         if (external) load_chunk<P, FULL>(Q.flux + off, n, j0, fl, 0.0);
     }
 
-    bool done = false;     // this profile needs no further iteration (uniform over its lane group)
+    // this profile needs no further iteration (uniform over its lane group)
+    constexpr bool PACKED = COOP_T && !COOP_ALWAYS;    // wavefronts that may carry profiles that were never active
+    bool done = PACKED ? !active : false;
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) {
-        if constexpr (!MULTI) done = false;
+        if constexpr (!MULTI && !PACKED) done = false;
         // A group that is done keeps executing (other groups of the wavefront may not be) but every update of
         // its state below is a select on `done`, so nothing of it changes any more.
         const bool seeded = (st & TG_ST_SEEDED) != 0;
@@ -576,8 +596,9 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         if (G::kBlock ? done : !__any(!done)) break;
     }
 
-    if constexpr (COOP) {
+    auto store_state_coop = [&](auto pred) {
         const bool turb = !Q.frozen_turb;
+        const uint64_t amask = decltype(pred)::value ? __ballot(active) : ~0ull;   // lanes whose profile was stepped
         wt.put(0, u + 1);
         if (turb) {
             wt.put(1, ue);
@@ -585,21 +606,30 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             wt.put(3, cE);
         }
         WaveTile::sync();
-        wt.flush(0, S_.u + off);
+        wt.template flush<decltype(pred)::value>(0, S_.u + woff, amask);
         if (turb) {
-            if (!external) wt.flush(1, S_.uE + off);
-            wt.flush(2, S_.DE + off);
-            wt.flush(3, S_.cE + off);
+            if (!external) wt.template flush<decltype(pred)::value>(1, S_.uE + woff, amask);
+            wt.template flush<decltype(pred)::value>(2, S_.DE + woff, amask);
+            wt.template flush<decltype(pred)::value>(3, S_.cE + woff, amask);
         }
-    } else {
+    };
+    auto store_state_lane = [&]() {
         store_chunk<P, FULL>(S_.u + off, n, j0, u + 1);
         if (!Q.frozen_turb) {
             if (!external) store_chunk<P, FULL>(S_.uE + off, n, j0, ue);
             store_chunk<P, FULL>(S_.DE + off, n, j0, DE);
             store_chunk<P, FULL>(S_.cE + off, n, j0, cE);
         }
+    };
+    if constexpr (COOP_ALWAYS) {
+        store_state_coop(std::false_type{});
+    } else if constexpr (COOP_T) {
+        if (coop) store_state_coop(std::true_type{});
+        else store_state_lane();
+    } else {
+        store_state_lane();
     }
-    if (t == 0) {
+    if (t == 0 && active) {
         S_.iters[b] = it0;
         S_.status[b] = st;
     }

@@ -68,14 +68,18 @@ struct WaveTile {
 #pragma unroll
         for (int k = 0; k < 4; ++k) tile_[256 * buf + pslot(k)] = make_double2(v[2 * k], v[2 * k + 1]);
     }
-    // tile `buf` -> coalesced nontemporal store of the 4 KiB row segment
-    __device__ __forceinline__ void flush(int buf, double *__restrict__ dst) const {
+    // tile `buf` -> coalesced nontemporal store of the 4 KiB row segment.  PRED: only the elements whose owning
+    // lane (element >> 2) has its bit set in `owners` are written.
+    template <bool PRED = false>
+    __device__ __forceinline__ void flush(int buf, double *__restrict__ dst, uint64_t owners = ~0ull) const {
         double2 *q = reinterpret_cast<double2 *>(dst) + lane_;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const double2 w = tile_[256 * buf + 64 * i + cslot_];
-            __builtin_nontemporal_store(w.x, &q[64 * i].x);
-            __builtin_nontemporal_store(w.y, &q[64 * i].y);
+            if (!PRED || ((owners >> ((64 * i + lane_) >> 2)) & 1)) {
+                __builtin_nontemporal_store(w.x, &q[64 * i].x);
+                __builtin_nontemporal_store(w.y, &q[64 * i].y);
+            }
         }
     }
 };

@@ -251,6 +251,32 @@ def test_multi_iteration_launch_equals_single_launches(tango, N, nb):
         assert np.allclose(A.err.to_host(), B.err.to_host(), rtol=1e-9, atol=1e-15)
 
 
+@pytest.mark.parametrize('N,nb', [(64, 37), (128, 21), (256, 11), (512, 5)])
+@pytest.mark.parametrize('k', [1, 5])
+def test_short_profiles_sharing_a_wavefront_vs_oracle(tango, N, nb, k):
+    """Several short profiles share a wavefront and its coalesced row I/O; they converge on different iterations
+    (some members sit out whole launches) and the odd ensemble size leaves a partly filled last wavefront.  Every
+    member against the CPU oracle run one profile at a time."""
+    from tango_amd.ensemble import OneFieldEnsemble, shestakov_ensemble
+    ens = shestakov_ensemble(nb, N)
+    tol, max_iter = 1e-9, 120
+    E = OneFieldEnsemble(ens, a_prof=1.0, tol=tol, max_iter=max_iter)
+    for _ in range(max_iter // k):
+        E.step(iters=k)
+    status, iters, err = E.status.to_host(), E.iters.to_host(), E.err.to_host()
+    assert np.all(status & 1) and not np.any(status & 6)
+    x = ens['x']
+    H7 = ens['S0'][:, None] * (x[None, :] < ens['delta'][:, None])
+    u, it, eh = orc.run_1f(ens['u0'], 1e4, ens['dx'], ens['nL'], np.ones(N), H7, 0.3, 1.0, tol, max_iter)
+    assert len(set(it.tolist())) > 2
+    for b in range(nb):
+        assert same_stop(int(iters[b]), int(it[b]), eh[b], tol, err[b]), b
+        if iters[b] == it[b]:
+            assert relerr(E.u.to_host()[b], u[b]) < TOL, b
+    m = int(min(iters.min(), it.min()))
+    assert np.allclose(err[:, :m], eh[:, :m], rtol=1e-6, atol=2e-12)
+
+
 TREAD_CASES = {'lightly': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.2}),
                'lightly_tight': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.05, 'innerFraction': 0.8}),
                'initially': dict(useTreadInitially=True, treadInitiallyParams={'numInitialSteps': 6, 'dtau': 0.3}),
