@@ -11,6 +11,7 @@
 #include "tg_host.h"
 #include "tg_io.h"
 #include "tg_solve.h"
+#include "tg_wave_io.h"
 
 namespace {
 
@@ -131,7 +132,13 @@ block3_solve_kernel(const double *__restrict__ Cb, const double *__restrict__ Bb
 // Fused Picard iteration of the three-field problem n, pi <-> pe
 // (examples/shestakov_threefield_nonlinearnu.py:52-149 on the stack of tango/solver.py:188-272)
 // ------------------------------------------------------------------------------------------
-template <int P, class G>
+// FULL: n = lanes x P and every array 16-byte aligned; one profile per wavefront or workgroup then moves its rows
+// coalesced through wavefront-private LDS tiles (tg_wave_io.h), four tiles per wavefront behind the group's
+// exchange area.
+constexpr int kTiles3f = 4;
+constexpr int kExch3f = 18;     // doubles per thread of the workgroup exchange area
+
+template <int P, class G, bool FULL>
 __global__ void __launch_bounds__(G::kBlock ? G::T : 256)
 picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     extern __shared__ double lds[];
@@ -157,21 +164,66 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     // grids of more than 512 points keep the reference's divisions (see tg_assemble.h)
     constexpr bool EXACT = (G::T * P > 512);
 
+    constexpr bool COOP = FULL && P == 4 && (G::kBlock || G::T == 64);
+    using Tile = WaveTile<4>;
+    Tile wt(lds + (COOP ? (G::kBlock ? kExch3f * G::T : 0) + (threadIdx.x >> 6) * kTiles3f * Tile::kDoubles : 0));
+    const int64_t woff = off + (G::kBlock ? (int64_t)(threadIdx.x >> 6) * 64 * P : 0);   // this wavefront's segment
+    const bool turb = !Q.frozen_turb;
+
     double u[3][P + 2], DE[3][P], cE[3][P];
+    double2 rE[3][2], rm[3][2];      // coalesced path: raw uE and u_{m-1} pieces, staged when they are needed
+    if constexpr (COOP) {
+        double2 ru[3][2], rD[3][2], rC[3][2];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        load_chunk<P, false>(S_.u[s] + off, n, j0, u[s] + 1, 1.0);
-        load_chunk<P, false>(S_.DE[s] + off, n, j0, DE[s], 0.0);
-        load_chunk<P, false>(S_.cE[s] + off, n, j0, cE[s], 0.0);
+        for (int s = 0; s < 3; ++s) {
+            wt.fetch(S_.u[s] + woff, ru[s]);
+            wt.fetch(S_.DE[s] + woff, rD[s]);
+            wt.fetch(S_.cE[s] + woff, rC[s]);
+        }
+        if (turb) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) wt.fetch(S_.uE[s] + woff, rE[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) wt.fetch(S_.um1[s] + woff, rm[s]);
+        wt.stage(0, ru[0]); wt.stage(1, ru[1]); wt.stage(2, ru[2]); wt.stage(3, rD[0]);
+        Tile::sync();
+        wt.take(0, u[0] + 1); wt.take(1, u[1] + 1); wt.take(2, u[2] + 1); wt.take(3, DE[0]);
+        Tile::sync();
+        wt.stage(0, rD[1]); wt.stage(1, rD[2]); wt.stage(2, rC[0]); wt.stage(3, rC[1]);
+        Tile::sync();
+        wt.take(0, DE[1]); wt.take(1, DE[2]); wt.take(2, cE[0]); wt.take(3, cE[1]);
+        Tile::sync();
+        wt.stage(0, rC[2]);
+        if (turb) {
+            wt.stage(1, rE[0]); wt.stage(2, rE[1]); wt.stage(3, rE[2]);
+        }
+        Tile::sync();
+        wt.take(0, cE[2]);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            load_chunk<P, false>(S_.u[s] + off, n, j0, u[s] + 1, 1.0);
+            load_chunk<P, false>(S_.DE[s] + off, n, j0, DE[s], 0.0);
+            load_chunk<P, false>(S_.cE[s] + off, n, j0, cE[s], 0.0);
+        }
     }
-    if (!Q.frozen_turb) {
+    if (turb) {
         double ue[3][P + 2];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            load_chunk<P, false>(S_.uE[s] + off, n, j0, ue[s] + 1, 1.0);
+            if constexpr (COOP) wt.take(1 + s, ue[s] + 1);
+            else load_chunk<P, false>(S_.uE[s] + off, n, j0, ue[s] + 1, 1.0);
 #pragma unroll
             for (int i = 0; i < P; ++i) ue[s][i + 1] = Q.a_prof * u[s][i + 1] + omp * (seeded ? ue[s][i + 1] : u[s][i + 1]);
-            store_chunk<P, false>(S_.uE[s] + off, n, j0, ue[s] + 1);
+            if constexpr (!COOP) store_chunk<P, false>(S_.uE[s] + off, n, j0, ue[s] + 1);
+        }
+        if constexpr (COOP) {
+            Tile::sync();
+            wt.put(1, ue[0] + 1); wt.put(2, ue[1] + 1); wt.put(3, ue[2] + 1);
+            Tile::sync();
+            wt.flush(1, S_.uE[0] + woff); wt.flush(2, S_.uE[1] + woff); wt.flush(3, S_.uE[2] + woff);
+            Tile::sync();
         }
         {
             double v[6], l[6], r[6];
@@ -221,12 +273,23 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
                 }
             }
         }
+        if constexpr (COOP) {
+            wt.put(0, DE[0]); wt.put(1, DE[1]); wt.put(2, DE[2]); wt.put(3, cE[0]);
+            Tile::sync();
+            wt.flush(0, S_.DE[0] + woff); wt.flush(1, S_.DE[1] + woff); wt.flush(2, S_.DE[2] + woff); wt.flush(3, S_.cE[0] + woff);
+            Tile::sync();
+            wt.put(0, cE[1]); wt.put(1, cE[2]);
+            Tile::sync();
+            wt.flush(0, S_.cE[1] + woff); wt.flush(1, S_.cE[2] + woff);
+        } else {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            store_chunk<P, false>(S_.DE[s] + off, n, j0, DE[s]);
-            store_chunk<P, false>(S_.cE[s] + off, n, j0, cE[s]);
+            for (int s = 0; s < 3; ++s) {
+                store_chunk<P, false>(S_.DE[s] + off, n, j0, DE[s]);
+                store_chunk<P, false>(S_.cE[s] + off, n, j0, cE[s]);
+            }
         }
     }
+    if constexpr (COOP) Tile::sync();
 
     // halos of H2 = DE, H3 = -cE and of the current profiles
     double h2l[3], h3l[3], h2r[3], h3r[3];
@@ -259,8 +322,15 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     }
 
     double um1[3][P];
+    if constexpr (COOP) {
+        wt.stage(0, rm[0]); wt.stage(1, rm[1]); wt.stage(2, rm[2]);
+        Tile::sync();
+        wt.take(0, um1[0]); wt.take(1, um1[1]); wt.take(2, um1[2]);
+        Tile::sync();
+    } else {
 #pragma unroll
-    for (int s = 0; s < 3; ++s) load_chunk<P, false>(S_.um1[s] + off, n, j0, um1[s], 0.0);
+        for (int s = 0; s < 3; ++s) load_chunk<P, false>(S_.um1[s] + off, n, j0, um1[s], 0.0);
+    }
     const double nu0 = Q.nu0[b];
     double UL[3];
 #pragma unroll
@@ -353,9 +423,15 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         xe[i] = xp[i].v[1];
         if (j0 + i < n) bad |= !(isfinite(xn[i]) && xn[i] >= 0.0 && isfinite(xi[i]) && xi[i] >= 0.0 && isfinite(xe[i]) && xe[i] >= 0.0);
     }
-    store_chunk<P, false>(S_.u[0] + off, n, j0, xn);
-    store_chunk<P, false>(S_.u[1] + off, n, j0, xi);
-    store_chunk<P, false>(S_.u[2] + off, n, j0, xe);
+    if constexpr (COOP) {
+        wt.put(0, xn); wt.put(1, xi); wt.put(2, xe);
+        Tile::sync();
+        wt.flush(0, S_.u[0] + woff); wt.flush(1, S_.u[1] + woff); wt.flush(2, S_.u[2] + woff);
+    } else {
+        store_chunk<P, false>(S_.u[0] + off, n, j0, xn);
+        store_chunk<P, false>(S_.u[1] + off, n, j0, xi);
+        store_chunk<P, false>(S_.u[2] + off, n, j0, xe);
+    }
     bad = g.any(bad | ((eln.singular | elp.singular) << 1));
     if (t == 0) {
         int ns = st;
@@ -416,8 +492,21 @@ struct Picard3fLauncher {
     static int go(int64_t nb, int n, hipStream_t s, const tg_state_3f *st, const tg_params_3f *q) {
         int grid, block;
         size_t lds;
-        geometry<G>(nb, grid, block, lds, 18);
-        hipLaunchKernelGGL((picard_3f_kernel<P, G>), dim3(grid), dim3(block), lds, s, *st, *q);
+        geometry<G>(nb, grid, block, lds, kExch3f);
+        uintptr_t al = 0;
+        for (int k = 0; k < 3; ++k)
+            al |= reinterpret_cast<uintptr_t>(st->u[k]) | reinterpret_cast<uintptr_t>(st->um1[k]) | reinterpret_cast<uintptr_t>(st->uE[k]) |
+                  reinterpret_cast<uintptr_t>(st->DE[k]) | reinterpret_cast<uintptr_t>(st->cE[k]);
+        const size_t tiles = (size_t)(block / 64) * kTiles3f * WaveTile<4>::kDoubles * sizeof(double);
+        const size_t cap = max_lds_bytes();
+        if (lds > cap) return fail(TG_ERR_UNSUPPORTED, "grid too large for the LDS of this device%s");
+        const bool full = (n == P * G::T) && (al & 15) == 0 && P == 4 && (G::kBlock || G::T == 64) && lds + tiles <= cap;
+        if (full) {
+            lds += tiles;
+            hipLaunchKernelGGL((picard_3f_kernel<P, G, true>), dim3(grid), dim3(block), lds, s, *st, *q);
+        } else {
+            hipLaunchKernelGGL((picard_3f_kernel<P, G, false>), dim3(grid), dim3(block), lds, s, *st, *q);
+        }
         return launch_check();
     }
 };

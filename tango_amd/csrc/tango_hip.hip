@@ -358,7 +358,8 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     double u[P + 2], ue[P], um1[P], DE[P], cE[P];
     double fl[GENERAL ? P : 1];
     const int64_t woff = off - (int64_t)((threadIdx.x & 63) / G::T) * S_.n;   // first profile of this wavefront
-    WaveTile wt(lds + (COOP_T ? (threadIdx.x >> 6) * 4 * kWaveTileDoubles : 0));
+    using Tile = WaveTile<8>;
+    Tile wt(lds + (COOP_T ? (threadIdx.x >> 6) * 4 * Tile::kDoubles : 0));
     auto load_state_coop = [&]() {
         double2 r0[4], r1[4], r2[4], r3[4], r4[4];
         wt.fetch(S_.u + woff, r0);
@@ -370,16 +371,16 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         wt.stage(1, r1);
         wt.stage(2, r2);
         wt.stage(3, r3);
-        WaveTile::sync();
+        Tile::sync();
         wt.take(0, u + 1);
         wt.take(1, ue);
         wt.take(2, DE);
         wt.take(3, cE);
-        WaveTile::sync();
+        Tile::sync();
         wt.stage(0, r4);
-        WaveTile::sync();
+        Tile::sync();
         wt.take(0, um1);
-        WaveTile::sync();
+        Tile::sync();
     };
     auto load_state_lane = [&]() {
         load_chunk<P, FULL>(S_.u + off, n, j0, u + 1, 0.0);
@@ -605,7 +606,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             wt.put(2, DE);
             wt.put(3, cE);
         }
-        WaveTile::sync();
+        Tile::sync();
         wt.template flush<decltype(pred)::value>(0, S_.u + woff, amask);
         if (turb) {
             if (!external) wt.template flush<decltype(pred)::value>(1, S_.uE + woff, amask);
@@ -693,7 +694,7 @@ struct Picard1fLauncher {
         const bool full = (n == P * G::T) && (al & 15) == 0;
         const bool general = q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly;
         const bool multi = q->iters_per_launch > 1;
-        if (kWaveCoop<P, G, true> && full) lds = (size_t)(block / 64) * 4 * kWaveTileDoubles * sizeof(double);
+        if (kWaveCoop<P, G, true> && full) lds = (size_t)(block / 64) * 4 * WaveTile<8>::kDoubles * sizeof(double);
 #define TG_LAUNCH_1F(F, GEN, M) hipLaunchKernelGGL((picard_1f_kernel<P, G, F, GEN, M>), dim3(grid), dim3(block), lds, s, *st, *q)
         if (general) {
             if (full) TG_LAUNCH_1F(true, true, true);

@@ -29,6 +29,14 @@ inline int launch_check() {
     return TG_OK;
 }
 
+// LDS bytes one workgroup may use on the current device (0 if the query fails)
+inline size_t max_lds_bytes() {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return 0;
+    return (size_t)v;
+}
+
 inline int pow2_at_least(int v) {
     int p = 1;
     while (p < v) p <<= 1;
