@@ -502,10 +502,10 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         double dtau = dt_full;
 #pragma unroll 1
         for (int attempt = 0;; ++attempt) {
-        ChunkElim<P> el;
+        ChunkElim<P, !EXACT> el;
         double hm2 = lane_first ? 0.0 : (h2l + h2first) / 2.0;
         double hm3 = lane_first ? 0.0 : (h3l + h3first) / 2.0;
-        double bm = fbeta_point(hm2, hm3, rc.dx);
+        double bm = fbeta_point<!EXACT>(hm2, hm3, rc.dx);
         double mx = 0.0, ss = 0.0;
         double h2c = h2first, h3c = h3first;
 #pragma unroll
@@ -518,7 +518,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             const double h3n = (i == P - 1) ? h3r : H3at(i < P - 1 ? i + 1 : 0);
             const double hp2 = (h2c + h2n) / 2.0;
             const double hp3 = (h3c + h3n) / 2.0;
-            const double bp = fbeta_point(hp2, hp3, rc.dx);
+            const double bp = fbeta_point<!EXACT>(hp2, hp3, rc.dx);
             const double H1 = Q.H1 ? Q.H1[jc] : 1.0;
             const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + jc] : ((j < src_cut) ? S0 : 0.0);
             double A, B, C, f;
@@ -544,7 +544,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         if (attempt == 0) {
             mx = g.max(mx);
             ss = g.sum(ss);
-            rms = sqrt(1.0 / (double)n * (ss / (mx * mx)));
+            rms = sqrt(1.0 / (double)n * quot<!EXACT>(ss, mx * mx));
         }
 
         double xt[P];

@@ -12,6 +12,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "tg_comm.h"
+
 namespace tg {
 
 // x / d, either as the division itself (EXACT) or as x * (1/d) with the reciprocal formed once
@@ -74,19 +76,20 @@ __device__ __forceinline__ void split_from_hats(double dh, double cHat, double d
 // The flux -(dp/dx)^3 / p^2 of tango/extras/shestakov_nonlinear_diffusion.py:59-60 pushed through the split above in
 // Cartesian geometry, from the single quotient r = (dp/dx)/p: DHat = -flux/(dp/dx) = r^2 (0 where dp/dx is 0),
 // cHat = flux/p = -r^3.  One division instead of three; DHat and cHat differ from the three-division values by
-// rounding only (a few ulp).
+// rounding only (a few ulp); the quotient itself is quot<true> of tg_comm.h.
 __device__ __forceinline__ void shestakov_split_point(double p, double dpdx, const Theta &th, double &D, double &c) {
-    const double r = dpdx / p;
+    const double r = quot<true>(dpdx, p);
     const double dh = r * r;
     split_from_hats(dh, -(dh * r), dpdx, th, D, c);
 }
 
 // tango/HToMatrixFD.py:277-297: adaptive upwinding weight at a half-integer grid point.
 // One division H2h/(c dx) serves both signs of c; the result is discarded where c == 0.
+template <bool FAST = false>
 __device__ __forceinline__ double fbeta_point(double H2h, double H3h, double dx) {
     const double gamma = 0.9;
     const double c = -H3h;
-    const double q = H2h / (c * dx);
+    const double q = quot<FAST>(H2h, c * dx);
     const double sp = 1.0 - q;   // betaStar for c > 0
     const double sn = -q;        // betaStar for c < 0
     const double bp = (sp <= 0.5) ? 0.5 : ((sp > 0.5) ? gamma * sp + (1.0 - gamma) : 0.0);

@@ -13,6 +13,34 @@
 
 namespace tg {
 
+// 1 / d and n / d without the scaling and fix-up steps of the IEEE sequence (12 issue slots -> 5 and 8): the
+// hardware estimate refined by two Newton steps, and one residual correction for the quotient.  Results are within
+// an ulp of the rounded ones as long as d and the quotient are normal numbers far from the exponent limits, which
+// holds for every divisor of the transport problem; a zero, infinite or NaN divisor gives NaN or infinity where
+// the true division would, so validity checks downstream see the same thing.  FAST = false is the division itself.
+template <bool FAST>
+__device__ __forceinline__ double recip(double d) {
+    if constexpr (FAST) {
+        double x = __builtin_amdgcn_rcp(d);
+        double e = __builtin_fma(-d, x, 1.0);
+        x = __builtin_fma(x, e, x);
+        e = __builtin_fma(-d, x, 1.0);
+        return __builtin_fma(x, e, x);
+    } else {
+        return 1.0 / d;
+    }
+}
+template <bool FAST>
+__device__ __forceinline__ double quot(double n, double d) {
+    if constexpr (FAST) {
+        const double x = recip<true>(d);
+        const double q = n * x;
+        return __builtin_fma(__builtin_fma(-d, q, n), x, q);
+    } else {
+        return n / d;
+    }
+}
+
 template <int LPP>
 struct WaveGroup {
     static constexpr int T = LPP;
@@ -61,6 +89,7 @@ struct WaveGroup {
     // dl_t = 1 + s_t + p_t (the row's diagonal-dominance slack) is carried along and every new diagonal is
     // formed as slack - s - p: for the M-matrices of the transport problem (s, p <= 0 <= dl) all those sums
     // have terms of one sign, so no cancellation eats the small slack as 1 - pm*s - sp*p would.
+    template <bool FAST = false>
     __device__ double pcr(double s, double p, double dl, double r, int &singular) const {
 #pragma unroll
         for (int h = 1; h < LPP; h <<= 1) {
@@ -73,7 +102,7 @@ struct WaveGroup {
             const double p2 = -(pp * p);
             const double g = d2 - s2 - p2;
             singular |= (g == 0.0);
-            const double inv = 1.0 / g;
+            const double inv = recip<FAST>(g);
             r = (r - rm * s - rp * p) * inv;
             s = s2 * inv;
             p = p2 * inv;
@@ -146,6 +175,7 @@ struct BlockGroup {
     }
     __device__ int any(int pred) const { return __syncthreads_or(pred); }
 
+    template <bool FAST = false>
     __device__ double pcr(double s, double p, double dl, double r, int &singular) const {
         // double-buffered rows in LDS: buffer k holds s,p,dl,r at lds_[k*4*T_ + {0,1,2,3}*T_ + t]
         int cur = 0;
@@ -165,7 +195,7 @@ struct BlockGroup {
             const double p2 = -(pp * p);
             const double g = d2 - s2 - p2;
             singular |= (g == 0.0);
-            const double inv = 1.0 / g;
+            const double inv = recip<FAST>(g);
             r = (r - rm * s - rp * p) * inv;
             s = s2 * inv;
             p = p2 * inv;

@@ -19,7 +19,8 @@
 
 namespace tg {
 
-template <int P>
+// FAST: reciprocals by recip<true> (tg_comm.h) instead of divisions.
+template <int P, bool FAST = false>
 struct ChunkElim {
     double e[P], f[P], l[P], rho[P];
     int singular = 0;
@@ -40,7 +41,7 @@ struct ChunkElim {
         const double t = dlt - c * rp;
         const double den = (t - a) + c * lp;
         singular |= (den == 0.0);
-        const double inv = 1.0 / den;
+        const double inv = recip<FAST>(den);
         e[i] = a * inv;
         f[i] = (d - c * fp) * inv;
         l[i] = -(c * lp) * inv;
@@ -73,7 +74,7 @@ struct ChunkElim {
             const double p2 = -(el * E0);
             const double gg = sig - s2 - p2;
             singular |= (gg == 0.0);
-            const double inv = 1.0 / gg;
+            const double inv = recip<FAST>(gg);
             s = s2 * inv;
             p = p2 * inv;
             dl = sig * inv;
@@ -84,7 +85,7 @@ struct ChunkElim {
             dl = rho[0];
             r = f[0];
         }
-        const double y = g.pcr(s, p, dl, r, singular);
+        const double y = g.template pcr<FAST>(s, p, dl, r, singular);
         x[P - 1] = y;
         if constexpr (P > 1) {
             // back substitution with the down-sweep rows, as a sequential Thomas sweep would do inside the
