@@ -410,24 +410,37 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         // A group that is done keeps executing (other groups of the wavefront may not be) but every update of
         // its state below is a select on `done`, so nothing of it changes any more.
         const bool seeded = (st & TG_ST_SEEDED) != 0;
+        // Only a wavefront shared by several profiles needs the selects: elsewhere `done` and `seeded` are uniform
+        // over the wavefront (workgroup), the loop is left as soon as `done` is set, and `seeded` is a branch.
+        constexpr bool kShared = !G::kBlock && G::T < 64;
+        const bool hold = kShared && done;
         if constexpr (GENERAL) {
             if (Q.pseudo_time) {
                 // the previous iterate takes the u_{m-1} slot (tango/solver.py:198-201); treadInitially's short
                 // pseudo-timestep for a profile's first iterations (:210-215)
 #pragma unroll
-                for (int i = 0; i < P; ++i) um1[i] = done ? um1[i] : u[i + 1];
+                for (int i = 0; i < P; ++i) um1[i] = hold ? um1[i] : u[i + 1];
                 rc = Recip(Q.dx, (it0 < Q.tread_initial_steps) ? Q.tread_initial_dtau : dt_full);
             }
         }
         if (!Q.frozen_turb) {
             // EWMA of the profile (tango/lodestro_method.py:345); with an external flux the caller has advanced it
             if (!external) {
+                if constexpr (kShared) {
 #pragma unroll
-                for (int i = 0; i < P; ++i) {
-                    const double v = Q.a_prof * u[i + 1] + omp * (seeded ? ue[i] : u[i + 1]);
-                    ue[i] = done ? ue[i] : v;
+                    for (int i = 0; i < P; ++i) {
+                        const double v = Q.a_prof * u[i + 1] + omp * (seeded ? ue[i] : u[i + 1]);
+                        ue[i] = hold ? ue[i] : v;
+                    }
+                } else if (seeded) {
+#pragma unroll
+                    for (int i = 0; i < P; ++i) ue[i] = Q.a_prof * u[i + 1] + omp * ue[i];
+                } else {     // the first iterate seeds the memory (tango/lodestro_method.py:706-708)
+#pragma unroll
+                    for (int i = 0; i < P; ++i) ue[i] = Q.a_prof * u[i + 1] + omp * u[i + 1];
                 }
             }
+            double Dn[P], cn[P];
             const double wl = g.from_left(ue[P - 1], 1, 0.0);
             const double wr = g.from_right(ue[0], 1, 0.0);
 #pragma unroll
@@ -455,11 +468,30 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                 } else {
                     shestakov_split_point(p, dpdx, th, D, c);   // built-in flux, Cartesian: one quotient
                 }
-                // EWMA of D and c (tango/lodestro_method.py:368-369)
-                const double nD = Q.a_turb * D + omt * (seeded ? DE[i] : D);
-                const double nc = Q.a_turb * c + omt * (seeded ? cE[i] : c);
-                DE[i] = done ? DE[i] : nD;
-                cE[i] = done ? cE[i] : nc;
+                Dn[i] = D;
+                cn[i] = c;
+            }
+            // EWMA of D and c (tango/lodestro_method.py:368-369)
+            if constexpr (kShared) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    const double nD = Q.a_turb * Dn[i] + omt * (seeded ? DE[i] : Dn[i]);
+                    const double nc = Q.a_turb * cn[i] + omt * (seeded ? cE[i] : cn[i]);
+                    DE[i] = hold ? DE[i] : nD;
+                    cE[i] = hold ? cE[i] : nc;
+                }
+            } else if (seeded) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    DE[i] = Q.a_turb * Dn[i] + omt * DE[i];
+                    cE[i] = Q.a_turb * cn[i] + omt * cE[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    DE[i] = Q.a_turb * Dn[i] + omt * Dn[i];
+                    cE[i] = Q.a_turb * cn[i] + omt * cn[i];
+                }
             }
         }
 
@@ -578,7 +610,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             bad |= (FULL || j0 + i < n) ? !(isfinite(x[i]) && x[i] >= 0.0) : 0;
-            u[i + 1] = done ? u[i + 1] : x[i];
+            u[i + 1] = hold ? u[i + 1] : x[i];
         }
         bad = g.any(bad | (singular << 1));
 

@@ -38,12 +38,15 @@ struct Theta {
         : Dmin(Dmin_), Dmax(Dmax_), thr(thr_), span(Dmax_ - Dmin_) {}
 };
 
-// The default theta rule of tango/lodestro_method.py:667-676.
-// NaN compares false everywhere, which leaves theta = 1 exactly as the reference's masks do.
+// The default theta rule of tango/lodestro_method.py:667-676.  NaN compares false everywhere, which leaves theta = 1 exactly as the reference's masks do.
+// c = (1-theta)*cHat cancels to ~1e-14 of theta's rounding, so theta must round exactly as the reference's division
+// does.  quot<true> qualifies: it is the arithmetic of the compiler's own IEEE division sequence (reciprocal
+// estimate, two Newton steps, quotient, residual correction) without that sequence's operand scaling and special-case
+// fix-up, which are no-ops for Dmax - DHat and Dmax - Dmin.
+template <bool FAST = false>
 __device__ __forceinline__ double theta_point(double dh, double dpdx, const Theta &th) {
     const bool small = fabs(dpdx) < th.thr;
-    // true division: c = (1-theta)*cHat cancels to ~1e-14 of theta's rounding, so theta must round as the reference's does
-    const double mid = (1.0 + (th.Dmax - dh) / th.span) / 2.0;
+    const double mid = (1.0 + quot<FAST>(th.Dmax - dh, th.span)) / 2.0;
     double tv = 1.0;
     tv = (dh < th.Dmin) ? 0.0 : tv;
     tv = (small && dh >= th.Dmin && dh <= th.Dmax) ? mid : tv;
@@ -67,8 +70,9 @@ __device__ __forceinline__ void flux_split_point(double flux, double p, double d
 }
 
 // D = theta DHat, c = (1 - theta) cHat (tango/lodestro_method.py:631-634) from DHat and cHat formed by the caller
+template <bool FAST = false>
 __device__ __forceinline__ void split_from_hats(double dh, double cHat, double dpdx, const Theta &th, double &D, double &c) {
-    const double tv = theta_point(dh, dpdx, th);
+    const double tv = theta_point<FAST>(dh, dpdx, th);
     D = tv * dh;
     c = (1.0 - tv) * cHat;
 }
@@ -80,7 +84,7 @@ __device__ __forceinline__ void split_from_hats(double dh, double cHat, double d
 __device__ __forceinline__ void shestakov_split_point(double p, double dpdx, const Theta &th, double &D, double &c) {
     const double r = quot<true>(dpdx, p);
     const double dh = r * r;
-    split_from_hats(dh, -(dh * r), dpdx, th, D, c);
+    split_from_hats<true>(dh, -(dh * r), dpdx, th, D, c);
 }
 
 // tango/HToMatrixFD.py:277-297: adaptive upwinding weight at a half-integer grid point.
@@ -92,8 +96,10 @@ __device__ __forceinline__ double fbeta_point(double H2h, double H3h, double dx)
     const double q = quot<FAST>(H2h, c * dx);
     const double sp = 1.0 - q;   // betaStar for c > 0
     const double sn = -q;        // betaStar for c < 0
-    const double bp = (sp <= 0.5) ? 0.5 : ((sp > 0.5) ? gamma * sp + (1.0 - gamma) : 0.0);
-    const double bn = (sn >= 0.5) ? 0.5 : ((sn < 0.5) ? gamma * sn : 0.0);
+    // A NaN betaStar (only from NaN coefficients) gives NaN here and 0 in the reference; either way the row it
+    // enters already holds NaN and the profile is reported invalid.
+    const double bp = (sp <= 0.5) ? 0.5 : gamma * sp + (1.0 - gamma);
+    const double bn = (sn >= 0.5) ? 0.5 : gamma * sn;
     return (c > 0.0) ? bp : ((c < 0.0) ? bn : 0.0);
 }
 
