@@ -426,7 +426,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         if (!Q.frozen_turb) {
             // EWMA of the profile (tango/lodestro_method.py:345); with an external flux the caller has advanced it
             if (!external) {
-                if constexpr (kShared) {
+                if constexpr (kShared || G::kBlock) {
 #pragma unroll
                     for (int i = 0; i < P; ++i) {
                         const double v = Q.a_prof * u[i + 1] + omp * (seeded ? ue[i] : u[i + 1]);
@@ -440,7 +440,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                     for (int i = 0; i < P; ++i) ue[i] = Q.a_prof * u[i + 1] + omp * u[i + 1];
                 }
             }
-            double Dn[P], cn[P];
+            double Dn[G::kBlock ? 1 : P], cn[G::kBlock ? 1 : P];
             const double wl = g.from_left(ue[P - 1], 1, 0.0);
             const double wr = g.from_right(ue[0], 1, 0.0);
 #pragma unroll
@@ -468,11 +468,17 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                 } else {
                     shestakov_split_point(p, dpdx, th, D, c);   // built-in flux, Cartesian: one quotient
                 }
-                Dn[i] = D;
-                cn[i] = c;
+                if constexpr (G::kBlock) {     // large grids are short of registers: update in place
+                    DE[i] = Q.a_turb * D + omt * (seeded ? DE[i] : D);
+                    cE[i] = Q.a_turb * c + omt * (seeded ? cE[i] : c);
+                } else {
+                    Dn[i] = D;
+                    cn[i] = c;
+                }
             }
             // EWMA of D and c (tango/lodestro_method.py:368-369)
-            if constexpr (kShared) {
+            if constexpr (G::kBlock) {
+            } else if constexpr (kShared) {
 #pragma unroll
                 for (int i = 0; i < P; ++i) {
                     const double nD = Q.a_turb * Dn[i] + omt * (seeded ? DE[i] : Dn[i]);
