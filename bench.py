@@ -81,8 +81,8 @@ def cpu_faithful(n, seconds=3.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=192)
+    ap.add_argument('--warmup', type=int, default=16)
     ap.add_argument('--iters-per-launch', type=int, default=16,
                     help='Picard iterations per kernel launch (profiles stay in registers in between); 1 = one launch per step')
     ap.add_argument('--check-every', type=int, default=16, help='steps between convergence-counter all-reduces')
