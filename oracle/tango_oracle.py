@@ -568,6 +568,28 @@ def picard_step_1f(st, dt, dx, UL, H1, H7, a_turb, a_prof, theta=THETA_DEFAULT, 
     return rms, profiles_invalid([st.u])
 
 
+def run_1f_timesteps(u0, tArray, dx, UL, H1, H7, a_turb, a_prof, tol, max_iter, theta=THETA_DEFAULT):
+    """The timestep loop of tango/solver.py:117-186 for one profile: each timestep iterates to convergence with
+    u_{m-1} = the previous converged profile; the EWMA memories persist across timesteps.  Returns the list of
+    (profile, iterations, errHistory) per timestep; stops after a timestep that did not converge."""
+    st = State1F(np.asarray(u0, dtype=float))
+    out = []
+    for m in range(1, len(tArray)):
+        dt = tArray[m] - tArray[m - 1]
+        st.um1 = st.u.copy()
+        err = []
+        done = bad = False
+        while len(err) < max_iter and not done and not bad:
+            rms, bad = picard_step_1f(st, dt, dx, UL, H1, H7, a_turb, a_prof, theta)
+            err.append(float(rms))
+            done = bool(rms < tol)
+            bad = bool(bad)
+        out.append((st.u.copy(), len(err), np.array(err)))
+        if not done:
+            break
+    return out
+
+
 def is_unacceptable(old, new, max_fractional_change=0.2, inner_fraction=0.5):
     """tango/solver.py:564-595: any point of the inner part of the profile changed by the given fraction or more."""
     k = int(inner_fraction * len(old))

@@ -293,6 +293,31 @@ def g12():
     save('g12_tread', **out)
 
 
+def g13():
+    """Several implicit timesteps of unequal length driven by the reference's own loop (tango/solver.py:117-186,
+    :533-548): EWMA memories persist from one timestep to the next, u_{m-1} is the previous converged profile."""
+    N = 128
+    dx = 1 / (N - 1); x = np.arange(N) * dx
+    th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
+    tArray = np.array([0.0, 0.02, 0.05, 0.1, 0.3])
+    n0 = 1 - 0.5 * x
+    lm = lodestro_method.lm(0.3, 1.0, th)
+    f0 = multifield.Field(label='n', rightBC=1e-2, profile_mminus1=n0.copy(), compute_all_H=ComputeAllH1F(1.0, 0.1), lodestroMethod=lm)
+    multifield.check_fields_initialize([f0])
+    call = multifield.ComputeAllHAllFields([f0], lodestro_method.TurbulenceHandler(dx, x, shest.AnalyticFluxModel(dx)))
+    s = tsolver.Solver(1, x, tArray, 400, 1e-10, call, [f0])
+    iters, errs, profs = [], [], []
+    while s.ok:
+        s.take_timestep()
+        iters.append(len(s.errHistoryFinal)); errs.append(s.errHistoryFinal.copy()); profs.append(s.profiles['n'].copy())
+    E = np.zeros((len(errs), max(iters)))
+    for k, e in enumerate(errs):
+        E[k, :len(e)] = e
+    print('timesteps', len(iters), 'iterations', iters, 'reachedEnd', s.reachedEnd)
+    save('g13_timesteps', N=N, tArray=tArray, n0=n0, iters=np.array(iters), errs=E, profiles=np.stack(profs),
+         reachedEnd=bool(s.reachedEnd), last_DE=lm._EWMATurbD._yEWMA_lminus1, last_uE=lm._EWMAProfile._yEWMA_lminus1)
+
+
 # ---------------------------------------------------------------- G9 three-field trajectories
 def run_ref_3f(N, nu0, BCs, a_turb, a_prof, tol, maxit, inner=0, dt=1e6, keep=()):
     dx = 1 / (N - 1); x = np.arange(N) * dx
@@ -384,6 +409,6 @@ def g11():
 
 
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12']
+    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13']
     for w in which:
         globals()[w]()

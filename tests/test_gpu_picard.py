@@ -335,3 +335,36 @@ def test_pseudo_timestep_control_ensemble(tango, golden):
         assert np.allclose(s.errHistory[b, :iters], err, rtol=1e-6, atol=6e-12), b
         assert relerr(s.profiles['n'][b], u) < TOL, b
     assert len(set(halvings)) > 2 and max(halvings) > 10     # the members really took different paths
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_several_timesteps(tango, golden, fused):
+    """tArray with four timesteps of unequal length: u_{m-1} and the EWMA memories carry over (tango/solver.py:117-186)."""
+    g = golden('g13_timesteps')
+    N = int(g['N'])
+    dx = 1 / (N - 1); x = np.arange(N) * dx
+    th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
+    sh = tango.extras.shestakov_nonlinear_diffusion
+    lm = tango.lodestro_method.lm(0.3, 1.0, th)
+    if fused:
+        cb = sh.ComputeAllH(1.0, 0.1)
+    else:
+        def cb(t, xx, profiles, HT):
+            return tango.multifield.HCoefficients(H1=np.ones_like(xx), H7=sh.GetSource(xx, 1.0, 0.1)) + HT
+    f = tango.multifield.Field(label='n', rightBC=1e-2, profile_mminus1=g['n0'].copy(), compute_all_H=cb, lodestroMethod=lm)
+    tango.multifield.check_fields_initialize([f])
+    call = tango.multifield.ComputeAllHAllFields([f], tango.lodestro_method.TurbulenceHandler(dx, x, sh.AnalyticFluxModel(dx)))
+    s = tango.solver.Solver(1, x, g['tArray'], 400, 1e-10, call, [f])
+    assert (s._fused is not None) == fused
+    m = 0
+    while s.ok:
+        s.take_timestep()
+        k = int(g['iters'][m])
+        assert same_stop(len(s.errHistoryFinal), k, g['errs'][m], 1e-10, s.errHistoryFinal), m
+        kk = min(k, len(s.errHistoryFinal))
+        assert np.allclose(s.errHistoryFinal[:kk], g['errs'][m, :kk], rtol=1e-6, atol=2e-12), m
+        # stopping one iteration apart at tol 1e-10 moves the profile by about that much
+        assert relerr(s.profiles['n'], g['profiles'][m]) < (TOL if len(s.errHistoryFinal) == k else 2e-9), m
+        m += 1
+    assert m == 4 and s.reachedEnd and bool(g['reachedEnd'])
+    assert abs(s.t - g['tArray'][-1]) < 1e-15

@@ -242,3 +242,14 @@ def test_g12_pseudo_timestep_control(golden):
         assert relerr(hist[:40], g[f'{tag}_first40']) < 1e-13
         assert np.allclose(err, g[f'{tag}_err'], rtol=1e-9, atol=1e-15)
         assert (halv.sum() > 0) == (tl is not None)
+
+
+def test_g13_timesteps(golden):
+    """Several timesteps of unequal length (tango/solver.py:117-186, :533-548)."""
+    g = golden('g13_timesteps')
+    N = int(g['N']); dx = 1 / (N - 1); x = np.arange(N) * dx
+    out = orc.run_1f_timesteps(g['n0'], g['tArray'], dx, 1e-2, np.ones(N), orc.shestakov_source(x, 1.0, 0.1), 0.3, 1.0, 1e-10, 400)
+    assert [o[1] for o in out] == g['iters'].tolist()
+    for m, (u, it, err) in enumerate(out):
+        assert relerr(u, g['profiles'][m]) < 1e-13
+        assert np.allclose(err, g['errs'][m, :it], rtol=1e-9, atol=1e-15)
