@@ -2,7 +2,7 @@
 
 Drop-in for the hot-path modules of sundials-codes/tango (`import tango_amd as tango`): tridiag,
 HToMatrixFD, JK_to_matrix_fd, lodestro_method, derivatives, smoother, multifield, fieldgroups, solver,
-extras.shestakov_nonlinear_diffusion, tango_logging.  All numerics run in hand-written HIP kernels
+extras.shestakov_nonlinear_diffusion, restart, tango_logging.  All numerics run in hand-written HIP kernels
 (tango_amd/csrc, built into tango_amd/lib/libtango_hip.so and bound with ctypes); there is no CPU
 fallback: importing the package without the built library fails."""
 from . import _hip  # noqa: F401  (raises ImportError when libtango_hip.so is missing)
@@ -14,5 +14,6 @@ from . import multifield, lodestro_method, fieldgroups  # noqa: F401
 from . import solver  # noqa: F401
 from . import extras  # noqa: F401
 from . import ensemble  # noqa: F401
+from . import restart  # noqa: F401
 
 __version__ = '0.1.0'

@@ -96,6 +96,8 @@ class Solver(object):
         self.normalizedResids = None
         self.datadict = None
         self.iterationsPerProfile = None
+        self.countLastTimestep = None
+        self.restart_profile_mminus1 = None
 
         first = np.asarray(self.profiles[fields[0].label])
         self.batched = first.ndim == 2
@@ -122,6 +124,8 @@ class Solver(object):
         (self.t, self.dt) = self._get_tdt(self.tArray, self.m)
         self.errHistory[:] = 0
         self._alloc_history()
+        # what a restart inside this timestep needs besides the profiles (tango_amd/restart.py)
+        self.restart_profile_mminus1 = {f.label: np.array(f.profile_mminus1, dtype=np.float64) for f in self.fields}
         tango_logging.info("Timestep m={}:  Beginning iteration loop ...".format(self.m))
 
         if self._fused is not None:
@@ -153,6 +157,7 @@ class Solver(object):
                     self.fluxesAllTimesteps[field.label][0] = self.fluxesAllIterations[field.label][0]
         for field in self.fields:
             field.profile_mminus1 = self.profiles[field.label]
+        self.countLastTimestep = self.iterationNumber      # iterations completed, counted from startIterationNumber
         self.iterationNumber = 0
         self.countStoredIterations = 0
 
@@ -464,7 +469,7 @@ class _Fused1F(object):
             self.status.set(st.astype(np.int32))
             H.check(H.lib.tg_memset(self.iters.ptr, 0, self.iters.nbytes, H.stream()))
             H.check(H.lib.tg_memset(self.err.ptr, 0, self.err.nbytes, H.stream()))
-        done = s.iterationNumber
+        done = self.start = s.iterationNumber
         hist = s.profilesAllIterations
         while done < s.maxIterations:
             k = 1 if hist is not None else min(s.iterationsPerCheck, s.maxIterations - done)
@@ -473,7 +478,7 @@ class _Fused1F(object):
             done += k
             if hist is not None:
                 snap = self.u.to_host()
-                hist[self.label][done - 1] = snap if s.batched else snap[0]
+                hist[self.label][done - 1 - self.start] = snap if s.batched else snap[0]
             H.check(H.lib.tg_status_reduce(self.status.ptr, self.nb, self.counts.ptr, H.stream()))
             active, conv, invalid, _ = (int(v) for v in self.counts.to_host())
             if active == 0:
@@ -486,8 +491,8 @@ class _Fused1F(object):
         err = self.err.to_host()
         u = self.u.to_host()
         s.iterationsPerProfile = iters.astype(np.int64)
-        s.iterationNumber = int(iters.max())
-        s.countStoredIterations = s.iterationNumber
+        s.countStoredIterations = int(iters.max())
+        s.iterationNumber = getattr(self, 'start', 0) + s.countStoredIterations
         s.converged = bool(np.all(status & H.ST_CONVERGED))
         s.solutionError = bool(np.any(status & H.ST_INVALID))
         s.profileStatus = status

@@ -106,3 +106,33 @@ def test_restart_from_ewma_iterates(tango):
     cont.take_timestep()
     assert relerr(cont.profiles['n'], a.profiles['n']) < 1e-12
     assert np.allclose(cont.errHistoryFinal, a.errHistoryFinal[12:30], rtol=1e-9, atol=1e-15)
+
+
+def test_restart_file_round_trip(tango, tmp_path, monkeypatch):
+    """tango/restart.py:59-98: interrupt a timestep after 12 iterations, write the state, continue in a new Solver
+    from the file with startIterationNumber; the result equals 30 iterations in one go."""
+    monkeypatch.chdir(tmp_path)
+    N = 256
+    x = np.arange(N) * (1 / (N - 1))
+    n0 = 1 - 0.5 * x
+    a = one_field_solver(tango, x, 1e-2, n0, maxit=30, tol=1e-30)
+    a.take_timestep()
+    part = one_field_solver(tango, x, 1e-2, n0, maxit=12, tol=1e-30)
+    part.take_timestep()
+    assert tango.restart.check_if_should_restart() is None
+    fn = tango.restart.write_state(part, basename='run', setNumber=0)
+    assert tango.restart.check_if_should_restart('run') == fn == tango.restart.check_if_should_restart()
+    setNumber, start, t, timestep, profs, pE, DE, cE = tango.restart.read_metadata_from_previousfile(fn)
+    assert (setNumber, start, timestep) == (1, 12, 1) and t == 1e4
+    um1 = tango.restart.read_profiles_mminus1(fn)['n']
+    assert np.array_equal(um1, n0)
+    cont = one_field_solver(tango, x, 1e-2, um1, maxit=30, tol=1e-30, ewma_iterates=(pE['n'], DE['n'], cE['n']),
+                            profiles=profs, startIterationNumber=start)
+    assert cont._fused is not None
+    cont.take_timestep()
+    assert cont.countLastTimestep == 30 and len(cont.errHistoryFinal) == 18
+    assert relerr(cont.profiles['n'], a.profiles['n']) < 1e-12
+    assert np.allclose(cont.errHistoryFinal, a.errHistoryFinal[12:30], rtol=1e-9, atol=1e-15)
+    fn2 = tango.restart.write_state(cont, basename='run', setNumber=setNumber)
+    assert tango.restart.find_latest_savefile('run') == fn2 == 'run_s1.npz'
+    assert tango.restart.read_metadata_from_previousfile(fn2)[1] == 30

@@ -136,3 +136,28 @@ def test_solver_constructor_and_ok_without_gpu():
     s.solutionError = False; s.iterationNumber = 10
     assert not s.ok
     assert tango.solver.Solver._get_tdt(np.array([0, 2.5, 10]), 2) == (10, 7.5)
+
+
+def test_restart_file_layout(tmp_path, monkeypatch):
+    """tango_amd.restart without a GPU: file naming, latest-file search and the reference's return tuple."""
+    import types
+    import tango_amd
+    monkeypatch.chdir(tmp_path)
+    ew = lambda v: types.SimpleNamespace(_yEWMA_lminus1=v)
+    lm = types.SimpleNamespace(_EWMAProfile=ew(np.full(4, 2.0)), _EWMATurbD=ew(np.full(4, 3.0)), _EWMATurbc=ew(np.full(4, 4.0)))
+    f = types.SimpleNamespace(label='n', lodestroMethod=lm)
+    s = types.SimpleNamespace(t=0.5, m=2, iterationNumber=0, countLastTimestep=7, fields=[f], profiles={'n': np.arange(4.0)},
+                              restart_profile_mminus1={'n': np.ones(4)})
+    assert tango_amd.restart.check_if_should_restart() is None
+    fn = tango_amd.restart.write_state(s, 'abc', 3)
+    assert fn == 'abc_s3.npz'
+    tango_amd.restart.write_state(s, 'abc', 11)
+    assert tango_amd.restart.find_latest_savefile('abc') == 'abc_s11.npz' == tango_amd.restart.check_if_should_restart()
+    out = tango_amd.restart.read_metadata_from_previousfile(fn)
+    assert out[:4] == (4, 7, 0.5, 2)
+    assert np.array_equal(out[4]['n'], np.arange(4.0)) and np.array_equal(out[5]['n'], np.full(4, 2.0))
+    assert np.array_equal(out[6]['n'], np.full(4, 3.0)) and np.array_equal(out[7]['n'], np.full(4, 4.0))
+    assert np.array_equal(tango_amd.restart.read_profiles_mminus1(fn)['n'], np.ones(4))
+    tango_amd.restart.write_state(s, 'other', 0)
+    with pytest.raises(ValueError):
+        tango_amd.restart.check_if_should_restart()
