@@ -59,6 +59,8 @@ class ComputeAllH(object):
     """compute_all_H callback of the one-field problem: H1 = 1, H7 = S0 [x < delta], plus the turbulent
     H2, H3.  S0 and delta may be (profiles,) arrays."""
 
+    static_H = True      # H1 and H7 depend on x only: the fused paths may evaluate them once
+
     def __init__(self, S0=1, delta=0.1):
         self.S0, self.delta = S0, delta
         self.fused_source = ('box', S0, delta)

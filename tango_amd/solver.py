@@ -387,20 +387,27 @@ def _plan_fused(s):
     if not isinstance(call, _mf.ComputeAllHAllFields) or type(call.turbhandler) is not _lm.TurbulenceHandler:
         return None
     th = call.turbhandler
-    if th.doSmoothing or th.isNonCartesian or call.fields is not s.fields and list(call.fields) != list(s.fields):
+    if call.fields is not s.fields and list(call.fields) != list(s.fields):
         return None
     for f in s.fields:
         m = f.lodestroMethod
         if type(f.gridMapper) is not _mf.GridsNull or type(m) is not _lm.lm:
             return None
-        sp = m._fluxSplitter
-        if sp.ftheta != sp._default_ftheta or np.ndim(sp.gxxAvg) or np.ndim(sp.gradxAvg) or sp.gxxAvg != 1 or sp.gradxAvg != 1:
+        if m._fluxSplitter.ftheta != m._fluxSplitter._default_ftheta:
             return None
+
+    def plain(sp):
+        return not (np.ndim(sp.gxxAvg) or np.ndim(sp.gradxAvg) or sp.gxxAvg != 1 or sp.gradxAvg != 1)
+
     model = getattr(th.fluxModel, 'fused_flux_model', None)
-    if model == 'shestakov' and len(s.fields) == 1 and s.fields[0].coupledTo is None and not s.useInnerIteration \
-            and getattr(s.fields[0].compute_all_H, 'fused_source', None) is not None \
-            and th.dxTurbGrid == s.dx and th.fluxModel.dx == s.dx:
+    one = len(s.fields) == 1 and s.fields[0].coupledTo is None and not s.useInnerIteration and th.dxTurbGrid == s.dx
+    if one and model == 'shestakov' and not th.doSmoothing and not th.isNonCartesian and plain(s.fields[0].lodestroMethod._fluxSplitter) \
+            and getattr(s.fields[0].compute_all_H, 'fused_source', None) is not None and th.fluxModel.dx == s.dx:
         return _Fused1F(s)
+    if one and getattr(s.fields[0].compute_all_H, 'static_H', False):
+        return _FusedExternal1F.plan(s)
+    if th.doSmoothing or th.isNonCartesian or not all(plain(f.lodestroMethod._fluxSplitter) for f in s.fields):
+        return None
     if s.useTreadLightly or s.useTreadInitially:
         return None      # pseudo-timestep control is built into the one-field kernel only
     if model == 'threefield_nonlinear_nu' and len(s.fields) == 3:
@@ -448,7 +455,8 @@ class _Fused1F(object):
         q = H.Params1F()
         q.dt, q.dx, q.a_turb, q.a_prof = float(s.dt), float(s.dx), float(a_turb), float(a_prof)
         q.Dmin, q.Dmax, q.dpdx_thr, q.tol = float(tp['Dmin']), float(tp['Dmax']), float(tp['dpdxThreshold']), float(s.tol)
-        q.UL, q.S0, q.src_cut = self.UL.ptr, self.S0.ptr, self.src_cut.ptr
+        ptr = lambda a: a.ptr if a is not None else None
+        q.UL, q.S0, q.src_cut = self.UL.ptr, ptr(self.S0), ptr(self.src_cut)
         q.flux_model, q.smooth_window, q.fixed_count, q.frozen_turb = H.FLUX_SHESTAKOV, 1, 0, 0
         # pseudo-timestep control (tango/solver.py:198-216, 311-372) runs inside the kernel
         q.pseudo_time = int(bool(s.useTreadLightly or s.useTreadInitially))
@@ -505,3 +513,117 @@ class _Fused1F(object):
         m = s.fields[0].lodestroMethod
         pick = (lambda a: a) if s.batched else (lambda a: a[0])
         m.set_ewma_iterates(pick(self.uE.to_host()), pick(self.DE.to_host()), pick(self.cE.to_host()))
+
+
+class _FusedExternal1F(_Fused1F):
+    """One field whose turbulent flux comes from a Python flux model (the place of a turbulence code): per
+    iteration the profile EWMA is advanced and handed to fluxModel.get_flux on the host, the (optionally smoothed)
+    flux goes back to the device and one launch of tg_picard_1f_step does the split, the EWMA of D and c, geometry
+    factors, assembly, residual, solve and validity check (tango/lodestro_method.py:327-408 + tango/solver.py:188-272).
+    Needs a compute_all_H callback marked `static_H = True`: its own H coefficients (H1 and optionally H7) depend on x
+    only, so they are evaluated once."""
+
+    @classmethod
+    def plan(cls, s):
+        f = s.fields[0]
+        Hs = f.compute_all_H(s.tArray[0], s.x, dict(s.profiles), _mf.HCoefficients())
+        if Hs.H1 is None or any(getattr(Hs, k) is not None for k in ('H2', 'H3', 'H4', 'H6', 'H8')):
+            return None
+        return cls(s, Hs)
+
+    def __init__(self, s, Hs):
+        f = s.fields[0]
+        self.label = f.label
+        u0 = np.atleast_2d(np.asarray(s.profiles[f.label], dtype=np.float64))
+        self.nb, self.n = nb, n = u0.shape
+        D = H.DeviceArray
+        self.u = D.from_host(u0)
+        self.um1 = D.from_host(np.atleast_2d(np.asarray(f.profile_mminus1, dtype=np.float64)))
+        self.uE, self.DE, self.cE = (D((nb, n), zero=True) for _ in range(3))
+        self.flux = D((nb, n), zero=True)
+        self.status = D((nb,), np.int32, zero=True)
+        self.iters = D((nb,), np.int32, zero=True)
+        self.err = D((nb, s.maxIterations), zero=True)
+        self.counts = D((4,), np.int64, zero=True)
+        self.UL = D.from_host(np.broadcast_to(np.asarray(f.rightBC, dtype=np.float64), (nb,)))
+        self.S0 = self.src_cut = None
+        self.uE_host = None
+        m = f.lodestroMethod
+        if m._EWMAProfile._yEWMA_lminus1 is not None:
+            self.uE_host = np.atleast_2d(np.array(m._EWMAProfile._yEWMA_lminus1, dtype=np.float64))
+            self.uE.set(self.uE_host)
+            self.DE.set(np.atleast_2d(m._EWMATurbD._yEWMA_lminus1))
+            self.cE.set(np.atleast_2d(m._EWMATurbc._yEWMA_lminus1))
+            self.status.set(np.full((nb,), H.ST_SEEDED, np.int32))
+        self.state = H.State1F(nb, n, self.u.ptr, self.um1.ptr, self.uE.ptr, self.DE.ptr, self.cE.ptr,
+                               self.status.ptr, self.iters.ptr, self.err.ptr, s.maxIterations)
+
+        def grid_array(v):       # (n,) device array of a coefficient shared by all profiles
+            v = np.asarray(v, dtype=np.float64)
+            if v.ndim > 1:
+                raise ValueError('geometry and H1 coefficients must be one array for the whole ensemble')
+            return D.from_host(np.broadcast_to(v, (n,)).copy())
+
+        self.H1 = grid_array(Hs.H1)
+        self.H7, self.h7_stride = None, 0
+        if Hs.H7 is not None:
+            h7 = np.asarray(Hs.H7, dtype=np.float64)
+            self.H7 = D.from_host(np.ascontiguousarray(h7))
+            self.h7_stride = n if h7.ndim == 2 else 0
+        th = s.compute_all_H_all_fields.turbhandler
+        sp = m._fluxSplitter
+        self.Vprime = self.gxx = self.gradx = None
+        if th.isNonCartesian:
+            self.Vprime, self.gxx, self.gradx = grid_array(th.VprimeTango), grid_array(th.gxxAvgTango), grid_array(th.gradxAvgTango)
+        self.gxx_turb = grid_array(sp.gxxAvg) if (np.ndim(sp.gxxAvg) or sp.gxxAvg != 1) else None
+        self.gradx_turb = grid_array(sp.gradxAvg) if (np.ndim(sp.gradxAvg) or sp.gradxAvg != 1) else None
+
+    def params(self, s):
+        q = _Fused1F.params(self, s)
+        p = lambda a: a.ptr if a is not None else None
+        q.S0 = q.src_cut = None
+        q.H1, q.H7, q.h7_stride = p(self.H1), p(self.H7), self.h7_stride
+        if self.H7 is None:          # no source: a zero array (the kernel's box source needs S0 and src_cut)
+            self.H7 = H.DeviceArray((self.n,), zero=True)
+            q.H7, q.h7_stride = self.H7.ptr, 0
+        q.Vprime, q.gxx, q.gradx = p(self.Vprime), p(self.gxx), p(self.gradx)
+        q.gxx_turb, q.gradx_turb = p(self.gxx_turb), p(self.gradx_turb)
+        q.flux_model, q.flux = H.FLUX_EXTERNAL, self.flux.ptr
+        return q
+
+    def run_timestep(self, s):
+        q = self.params(s)
+        q.iters_per_launch = 1
+        th = s.compute_all_H_all_fields.turbhandler
+        a_prof = s.fields[0].lodestroMethod.get_ewma_params()[1]
+        if s.m > 1:
+            self.um1.copy_from(self.u)
+            self.status.set((self.status.to_host() & H.ST_SEEDED).astype(np.int32))
+            H.check(H.lib.tg_memset(self.iters.ptr, 0, self.iters.nbytes, H.stream()))
+            H.check(H.lib.tg_memset(self.err.ptr, 0, self.err.nbytes, H.stream()))
+        done = self.start = s.iterationNumber
+        hist = s.profilesAllIterations
+        pick = (lambda a: a) if s.batched else (lambda a: a[0])
+        while done < s.maxIterations:
+            status = self.status.to_host()
+            active = (status & (H.ST_CONVERGED | H.ST_INVALID)) == 0
+            if not active.any():
+                break
+            # host side of the protocol: EWMA of the profiles that still iterate, flux model, smoothing
+            u = self.u.to_host()
+            if self.uE_host is None:
+                self.uE_host = u.copy()
+            new = a_prof * u + (1 - a_prof) * self.uE_host
+            self.uE_host[active] = new[active]
+            flux = np.asarray(th.fluxModel.get_flux({self.label: pick(self.uE_host)})[self.label], dtype=np.float64)
+            if th.doSmoothing:
+                flux = np.asarray(th.fluxSmoother.smooth(flux), dtype=np.float64)
+            self.uE.set(self.uE_host)
+            self.flux.set(np.atleast_2d(flux))
+            H.check(H.lib.tg_picard_1f_step(C.byref(self.state), C.byref(q), H.stream()))
+            done += 1
+            if hist is not None:
+                hist[self.label][done - 1 - self.start] = pick(self.u.to_host())
+                if s.fluxesAllIterations is not None:
+                    s.fluxesAllIterations[self.label][done - 1 - self.start] = flux
+        self.finish(s)

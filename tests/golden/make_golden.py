@@ -318,6 +318,54 @@ def g13():
          reachedEnd=bool(s.reachedEnd), last_DE=lm._EWMATurbD._yEWMA_lminus1, last_uE=lm._EWMAProfile._yEWMA_lminus1)
 
 
+class PowerLawFlux(object):
+    """Flux model in the manner of examples/stripped_down_tango_example.py:55-65: Gamma = -D0 |n'/n|^p n'."""
+    def __init__(self, dx, D0=0.7, p=1.5):
+        self.dx, self.D0, self.p = dx, D0, p
+
+    def get_flux(self, profiles):
+        n = profiles['n']
+        dn = derivatives.dx_centered_difference_edge_first_order(n, self.dx)
+        return {'n': -self.D0 * np.abs(dn / n) ** self.p * dn}
+
+
+class ComputeAllHGeom(object):
+    def __init__(self, Vp, S):
+        self.Vp, self.S = Vp, S
+
+    def __call__(self, t, x, profiles, HCoeffsTurb):
+        return multifield.HCoefficients(H1=1.0 * self.Vp, H7=self.Vp * self.S) + HCoeffsTurb
+
+
+def g14():
+    """One field in non-Cartesian geometry with a flux model supplied as a Python object and a smoothed flux: V',
+    <g^xx>, <|grad x|> on the transport grid (TurbulenceHandler) and on the turbulence grid (lm), H1 = V',
+    H7 = V' S (tango/lodestro_method.py:280-408,540-638)."""
+    N = 200
+    dx = 1 / (N - 1); x = np.arange(N) * dx
+    Vp = 1.0 + x; gxx = 1.0 + 0.2 * x ** 2; gradx = np.sqrt(gxx)
+    S = 1.0 * (x < 0.15)
+    th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
+    out = dict(N=N, Vp=Vp, gxx=gxx, gradx=gradx, S=S)
+    for tag, window in (('plain', None), ('smooth', 7)):
+        lm = lodestro_method.lm(0.2, 0.6, th, gxxAvgTurb=gxx, gradxAvgTurb=gradx)
+        sm = smoother.Smoother(window) if window else None
+        turb = lodestro_method.TurbulenceHandler(dx, x, PowerLawFlux(dx), VprimeTango=Vp, fluxSmoother=sm, gxxAvgTango=gxx,
+                                                 gradxAvgTango=gradx)
+        f0 = multifield.Field(label='n', rightBC=0.05, profile_mminus1=1 - 0.6 * x, compute_all_H=ComputeAllHGeom(Vp, S), lodestroMethod=lm)
+        multifield.check_fields_initialize([f0])
+        # the smoothed flux does not settle below 1e-2 on this problem: compare a fixed 40 iterations of it
+        s = tsolver.Solver(1, x, np.array([0, 50.0]), 40 if window else 600, 1e-10, multifield.ComputeAllHAllFields([f0], turb), [f0])
+        while s.ok:
+            s.take_timestep()
+        k = len(s.errHistoryFinal)
+        print(tag, 'iterations', k, 'converged', s.converged)
+        out.update({f'{tag}_iters': k, f'{tag}_err': s.errHistoryFinal.copy(), f'{tag}_final': s.profiles['n'].copy(),
+                    f'{tag}_it3': s.profilesAllIterations['n'][3].copy(), f'{tag}_last_DE': lm._EWMATurbD._yEWMA_lminus1,
+                    f'{tag}_last_cE': lm._EWMATurbc._yEWMA_lminus1, f'{tag}_conv': bool(s.converged)})
+    save('g14_geometry', **out)
+
+
 # ---------------------------------------------------------------- G9 three-field trajectories
 def run_ref_3f(N, nu0, BCs, a_turb, a_prof, tol, maxit, inner=0, dt=1e6, keep=()):
     dx = 1 / (N - 1); x = np.arange(N) * dx
@@ -409,6 +457,6 @@ def g11():
 
 
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13']
+    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14']
     for w in which:
         globals()[w]()

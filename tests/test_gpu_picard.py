@@ -368,3 +368,143 @@ def test_several_timesteps(tango, golden, fused):
         m += 1
     assert m == 4 and s.reachedEnd and bool(g['reachedEnd'])
     assert abs(s.t - g['tArray'][-1]) < 1e-15
+
+
+@pytest.mark.parametrize('N,nb', [(256, 3), (512, 2), (200, 2), (1024, 1)])
+@pytest.mark.parametrize('external', [False, True])
+def test_geometry_arrays_and_external_flux(tango, N, nb, external):
+    """The production shape of the step (tango/lodestro_method.py:327-408 with V', <g^xx>, <|grad x|> on both grids,
+    H1 = V', a source array per profile) with the built-in flux and with a flux array supplied from outside between
+    launches, as a turbulence code would (the caller advances the profile EWMA itself then).  Against the oracle."""
+    from tango_amd import _hip as H
+    from tango_amd.ensemble import OneFieldEnsemble, shestakov_ensemble
+    ens = shestakov_ensemble(nb, N)
+    x, dx = ens['x'], ens['dx']
+    Vp = 1.0 + x
+    gxx = 1.0 + 0.2 * x ** 2
+    gradx = np.sqrt(gxx)
+    H7 = Vp[None, :] * ens['S0'][:, None] * (x[None, :] < ens['delta'][:, None])
+    a_turb, a_prof, iters = 0.3, 0.5, 14
+    E = OneFieldEnsemble(ens, a_turb=a_turb, a_prof=a_prof, tol=1e-30, max_iter=iters, fixed_count=True)
+    dev = {k: H.DeviceArray.from_host(v) for k, v in dict(Vp=Vp, gxx=gxx, gradx=gradx, H7=H7).items()}
+    q = E.params
+    q.H1, q.H7, q.h7_stride = dev['Vp'].ptr, dev['H7'].ptr, N
+    q.Vprime, q.gxx, q.gradx, q.gxx_turb, q.gradx_turb = dev['Vp'].ptr, dev['gxx'].ptr, dev['gradx'].ptr, dev['gxx'].ptr, dev['gradx'].ptr
+    flux_dev = H.DeviceArray((nb, N), zero=True)
+    if external:
+        q.flux_model, q.flux = H.FLUX_EXTERNAL, flux_dev.ptr
+    states = [orc.State1F(ens['u0'][b]) for b in range(nb)]
+    uE = None
+    for it in range(iters):
+        if external:     # the caller's side of the protocol: advance the profile EWMA, evaluate the flux on it
+            u = E.u.to_host()
+            uE = a_prof * u + (1 - a_prof) * (u if uE is None else uE)
+            E.uE.set(uE)
+            flux_dev.set(orc.shestakov_flux(uE, dx))
+        E.step()
+        errs = []
+        for b in range(nb):
+            rms, bad = orc.picard_step_1f(states[b], 1e4, dx, ens['nL'][b], Vp, H7[b], a_turb, a_prof, Vprime=Vp, gxx=gxx,
+                                          gradx=gradx, gxx_turb=gxx, gradx_turb=gradx)
+            errs.append(rms)
+            assert not bad
+        if it in (0, 1, 5, iters - 1):
+            got = {k: getattr(E, k).to_host() for k in ('u', 'uE', 'DE', 'cE')}
+            for b in range(nb):
+                st = states[b]
+                for k, ref in (('u', st.u), ('uE', st.uE), ('DE', st.DE), ('cE', st.cE)):
+                    assert relerr(got[k][b], ref) < TOL, (it, b, k)
+            assert np.allclose(E.err.to_host()[:, it], errs, rtol=1e-6, atol=2e-12)
+    assert not np.any(E.status.to_host() & 6)
+
+
+class PowerLawFlux(object):
+    """Gamma = -D0 |n'/n|^p n', a flux model given as a Python object (examples/stripped_down_tango_example.py:55-65)."""
+    def __init__(self, tango, dx, D0=0.7, p=1.5):
+        self.d, self.dx, self.D0, self.p = tango.derivatives.dx_centered_difference_edge_first_order, dx, D0, p
+
+    def get_flux(self, profiles):
+        n = profiles['n']
+        dn = self.d(n, self.dx)
+        return {'n': -self.D0 * np.abs(dn / n) ** self.p * dn}
+
+
+class ComputeAllHGeom(object):
+    def __init__(self, tango, Vp, S, static):
+        self.t, self.Vp, self.S = tango, Vp, S
+        if static:
+            self.static_H = True
+
+    def __call__(self, t, x, profiles, HCoeffsTurb):
+        return self.t.multifield.HCoefficients(H1=1.0 * self.Vp, H7=self.Vp * self.S) + HCoeffsTurb
+
+
+@pytest.mark.parametrize('tag', ['plain', 'smooth'])
+@pytest.mark.parametrize('fused', [True, False])
+def test_python_flux_model_in_noncartesian_geometry(tango, golden, tag, fused):
+    """The shape of a production run: flux from a Python object each iteration (optionally smoothed), V', <g^xx>,
+    <|grad x|> on both grids, H1 = V'.  Fused: host flux model + one kernel launch per iteration; generic: one
+    kernel per operation.  Both against the reference's trajectory."""
+    g = golden('g14_geometry')
+    N = int(g['N'])
+    dx = 1 / (N - 1); x = np.arange(N) * dx
+    th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
+    lm = tango.lodestro_method.lm(0.2, 0.6, th, gxxAvgTurb=g['gxx'], gradxAvgTurb=g['gradx'])
+    sm = tango.smoother.Smoother(7) if tag == 'smooth' else None
+    turb = tango.lodestro_method.TurbulenceHandler(dx, x, PowerLawFlux(tango, dx), VprimeTango=g['Vp'], fluxSmoother=sm,
+                                                   gxxAvgTango=g['gxx'], gradxAvgTango=g['gradx'])
+    f = tango.multifield.Field(label='n', rightBC=0.05, profile_mminus1=1 - 0.6 * x,
+                               compute_all_H=ComputeAllHGeom(tango, g['Vp'], g['S'], fused), lodestroMethod=lm)
+    tango.multifield.check_fields_initialize([f])
+    s = tango.solver.Solver(1, x, np.array([0, 50.0]), 40 if sm else 600, 1e-10, tango.multifield.ComputeAllHAllFields([f], turb), [f])
+    assert (s._fused is not None) == fused
+    while s.ok:
+        s.take_timestep()
+    k = int(g[f'{tag}_iters'])
+    assert bool(s.converged) == bool(g[f'{tag}_conv'])
+    assert same_stop(len(s.errHistoryFinal), k, g[f'{tag}_err'], 1e-10, s.errHistoryFinal)
+    m = min(k, len(s.errHistoryFinal))
+    assert np.allclose(s.errHistoryFinal[:m], g[f'{tag}_err'][:m], rtol=1e-6, atol=5e-12)
+    assert relerr(s.profilesAllIterations['n'][3], g[f'{tag}_it3']) < TOL
+    if len(s.errHistoryFinal) == k:
+        assert relerr(s.profiles['n'], g[f'{tag}_final']) < TOL
+        assert relerr(lm._EWMATurbD._yEWMA_lminus1, g[f'{tag}_last_DE']) < TOL
+        assert relerr(lm._EWMATurbc._yEWMA_lminus1, g[f'{tag}_last_cE']) < TOL
+
+
+def test_python_flux_model_ensemble(tango, golden):
+    """An ensemble through the Python-flux-model path: members stop on their own iterations (their profile EWMA and
+    flux freeze with them); every member against the oracle run alone."""
+    g = golden('g14_geometry')
+    N = int(g['N'])
+    dx = 1 / (N - 1); x = np.arange(N) * dx
+    th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
+    bcs = np.array([0.05, 0.08, 0.03, 0.12])
+    ics = np.stack([1 - 0.6 * x, 1.2 - 0.7 * x, 0.9 - 0.5 * x, 1 - 0.4 * x])
+    lm = tango.lodestro_method.lm(0.2, 0.6, th, gxxAvgTurb=g['gxx'], gradxAvgTurb=g['gradx'])
+    turb = tango.lodestro_method.TurbulenceHandler(dx, x, PowerLawFlux(tango, dx), VprimeTango=g['Vp'], gxxAvgTango=g['gxx'],
+                                                   gradxAvgTango=g['gradx'])
+    f = tango.multifield.Field(label='n', rightBC=bcs, profile_mminus1=ics, compute_all_H=ComputeAllHGeom(tango, g['Vp'], g['S'], True),
+                               lodestroMethod=lm)
+    tango.multifield.check_fields_initialize([f])
+    s = tango.solver.Solver(1, x, np.array([0, 50.0]), 600, 1e-9, tango.multifield.ComputeAllHAllFields([f], turb), [f])
+    assert s._fused is not None and s.batched
+    s.take_timestep()
+    assert s.converged
+    flux_fn = lambda n: -0.7 * np.abs(orc.ddx_edge1(n, dx) / n) ** 1.5 * orc.ddx_edge1(n, dx)
+    its = []
+    for b in range(len(bcs)):
+        st = orc.State1F(ics[b])
+        err = []
+        while True:
+            rms, bad = orc.picard_step_1f(st, 50.0, dx, bcs[b], g['Vp'], g['Vp'] * g['S'], 0.2, 0.6, flux_fn=flux_fn, Vprime=g['Vp'],
+                                          gxx=g['gxx'], gradx=g['gradx'], gxx_turb=g['gxx'], gradx_turb=g['gradx'])
+            err.append(rms)
+            if rms < 1e-9 or len(err) >= 600:
+                break
+        its.append(len(err))
+        assert same_stop(int(s.iterationsPerProfile[b]), len(err), np.array(err), 1e-9, s.errHistory[b]), b
+        if int(s.iterationsPerProfile[b]) == len(err):
+            assert relerr(s.profiles['n'][b], st.u) < TOL, b
+            assert relerr(lm._EWMAProfile._yEWMA_lminus1[b], st.uE) < TOL, b
+    assert len(set(its)) > 1
