@@ -133,7 +133,7 @@ def main():
 
     def fence():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     run(args.warmup)
@@ -214,7 +214,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args.n, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 
