@@ -164,16 +164,17 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     // grids of more than 512 points keep the reference's divisions (see tg_assemble.h)
     constexpr bool EXACT = (G::T * P > 512);
 
-    constexpr bool COOP = FULL && P == 4 && (G::kBlock || G::T == 64);
-    using Tile = WaveTile<4>;
+    constexpr bool COOP = FULL && (P == 4 || P == 8) && (G::kBlock || G::T == 64);
+    using Tile = WaveTile<(P == 8) ? 8 : 4>;
+    constexpr int KP = Tile::KP;
     Tile wt(lds + (COOP ? (G::kBlock ? kExch3f * G::T : 0) + (threadIdx.x >> 6) * kTiles3f * Tile::kDoubles : 0));
     const int64_t woff = off + (G::kBlock ? (int64_t)(threadIdx.x >> 6) * 64 * P : 0);   // this wavefront's segment
     const bool turb = !Q.frozen_turb;
 
     double u[3][P + 2], DE[3][P], cE[3][P];
-    double2 rE[3][2], rm[3][2];      // coalesced path: raw uE and u_{m-1} pieces, staged when they are needed
+    double2 rE[3][KP], rm[3][KP];      // coalesced path: raw uE and u_{m-1} pieces, staged when they are needed
     if constexpr (COOP) {
-        double2 ru[3][2], rD[3][2], rC[3][2];
+        double2 ru[3][KP], rD[3][KP], rC[3][KP];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             wt.fetch(S_.u[s] + woff, ru[s]);
@@ -497,10 +498,10 @@ struct Picard3fLauncher {
         for (int k = 0; k < 3; ++k)
             al |= reinterpret_cast<uintptr_t>(st->u[k]) | reinterpret_cast<uintptr_t>(st->um1[k]) | reinterpret_cast<uintptr_t>(st->uE[k]) |
                   reinterpret_cast<uintptr_t>(st->DE[k]) | reinterpret_cast<uintptr_t>(st->cE[k]);
-        const size_t tiles = (size_t)(block / 64) * kTiles3f * WaveTile<4>::kDoubles * sizeof(double);
+        const size_t tiles = (size_t)(block / 64) * kTiles3f * WaveTile<(P == 8) ? 8 : 4>::kDoubles * sizeof(double);
         const size_t cap = max_lds_bytes();
         if (lds > cap) return fail(TG_ERR_UNSUPPORTED, "grid too large for the LDS of this device%s");
-        const bool full = (n == P * G::T) && (al & 15) == 0 && P == 4 && (G::kBlock || G::T == 64) && lds + tiles <= cap;
+        const bool full = (n == P * G::T) && (al & 15) == 0 && (P == 4 || P == 8) && (G::kBlock || G::T == 64) && lds + tiles <= cap;
         if (full) {
             lds += tiles;
             hipLaunchKernelGGL((picard_3f_kernel<P, G, true>), dim3(grid), dim3(block), lds, s, *st, *q);
