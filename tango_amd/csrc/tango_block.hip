@@ -261,14 +261,14 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             } else {
                 // the same through the quotient r = (dpi/dx)/pi: DHat = -flux/(du/dx) = r^2 for every field (0 where
                 // du/dx is 0), cHat = flux/u = -r^2 (du/dx)/u, which for pi itself is -r^3
-                const double r = dd[1] / pi;
+                const double r = quot<true>(dd[1], pi);
                 const double Dsh = r * r;
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
                     const double dh = (dd[s] == 0.0) ? 0.0 : Dsh;
-                    const double cHat = (s == 1) ? -(Dsh * r) : -(Dsh * dd[s]) / ue[s][i + 1];
+                    const double cHat = (s == 1) ? -(Dsh * r) : quot<true>(-(Dsh * dd[s]), ue[s][i + 1]);
                     double D, c;
-                    split_from_hats(dh, cHat, dd[s], th, D, c);
+                    split_from_hats<true>(dh, cHat, dd[s], th, D, c);
                     DE[s][i] = Q.a_turb * D + omt * (seeded ? DE[s][i] : D);
                     cE[s][i] = Q.a_turb * c + omt * (seeded ? cE[s][i] : c);
                 }
@@ -337,8 +337,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) UL[s] = Q.UL[s][b];
 
-    ChunkElim<P> eln;
-    BlockElim<2, P> elp;
+    ChunkElim<P, !EXACT> eln;
+    BlockElim<2, P, !EXACT> elp;
     double hm2[3], hm3[3], bm[3], h2c[3], h3c[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -346,7 +346,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         h3c[s] = -cE[s][0];
         hm2[s] = lane_first ? 0.0 : (h2l[s] + h2c[s]) / 2.0;
         hm3[s] = lane_first ? 0.0 : (h3l[s] + h3c[s]) / 2.0;
-        bm[s] = fbeta_point(hm2[s], hm3[s], rc.dx);
+        bm[s] = fbeta_point<!EXACT>(hm2[s], hm3[s], rc.dx);
     }
     double mx[3] = {0.0, 0.0, 0.0}, ss[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -356,8 +356,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         const bool last = (j == n - 1);
         const int jc = valid ? j : n - 1;
         // collisional coupling nu = nu0 / ((pi + pe)/n)^{3/2} from the current profiles (example :108-110)
-        const double q = u[1][i + 1] / u[0][i + 1] + u[2][i + 1] / u[0][i + 1];
-        const double nu = nu0 / (q * sqrt(q));
+        const double q = quot<!EXACT>(u[1][i + 1], u[0][i + 1]) + quot<!EXACT>(u[2][i + 1], u[0][i + 1]);
+        const double nu = quot<!EXACT>(nu0, q * sqrt(q));
         double A[3], B[3], C[3], f[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -365,7 +365,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             const double h3n = (i == P - 1) ? h3r[s] : -cE[s][i < P - 1 ? i + 1 : 0];
             const double hp2 = (h2c[s] + h2n) / 2.0;
             const double hp3 = (h3c[s] + h3n) / 2.0;
-            const double bp = fbeta_point(hp2, hp3, rc.dx);
+            const double bp = fbeta_point<!EXACT>(hp2, hp3, rc.dx);
             const double h6 = (s == 0) ? 0.0 : -nu;       // H6 = -nu for pi and pe (example :125, :144)
             fd_row<EXACT>(last, 1.0, um1[s][i], rc, UL[s], hm2[s], hm3[s], bm[s], hp2, hp3, bp, 0.0, h6, Q.H7[s][jc], A[s], B[s],
                          C[s], f[s]);

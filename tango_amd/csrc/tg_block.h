@@ -127,16 +127,18 @@ __device__ __forceinline__ void diag_from_rowsum(Mat<K> &G, const Vec<K> &rs) {
     }
 }
 
+template <bool FAST = false>
 __device__ __forceinline__ Mat<1> inverse(const Mat<1> &x, int &singular) {
     singular |= (x.m[0][0] == 0.0);
     Mat<1> r;
-    r.m[0][0] = 1.0 / x.m[0][0];
+    r.m[0][0] = recip<FAST>(x.m[0][0]);
     return r;
 }
+template <bool FAST = false>
 __device__ __forceinline__ Mat<2> inverse(const Mat<2> &x, int &singular) {
     const double det = x.m[0][0] * x.m[1][1] - x.m[0][1] * x.m[1][0];
     singular |= (det == 0.0);
-    const double inv = 1.0 / det;
+    const double inv = recip<FAST>(det);
     Mat<2> r;
     r.m[0][0] = x.m[1][1] * inv;
     r.m[0][1] = -x.m[0][1] * inv;
@@ -144,13 +146,14 @@ __device__ __forceinline__ Mat<2> inverse(const Mat<2> &x, int &singular) {
     r.m[1][1] = x.m[0][0] * inv;
     return r;
 }
+template <bool FAST = false>
 __device__ __forceinline__ Mat<3> inverse(const Mat<3> &x, int &singular) {
     const double c00 = x.m[1][1] * x.m[2][2] - x.m[1][2] * x.m[2][1];
     const double c01 = x.m[1][2] * x.m[2][0] - x.m[1][0] * x.m[2][2];
     const double c02 = x.m[1][0] * x.m[2][1] - x.m[1][1] * x.m[2][0];
     const double det = x.m[0][0] * c00 + x.m[0][1] * c01 + x.m[0][2] * c02;
     singular |= (det == 0.0);
-    const double inv = 1.0 / det;
+    const double inv = recip<FAST>(det);
     Mat<3> r;
     r.m[0][0] = c00 * inv;
     r.m[1][0] = c01 * inv;
@@ -201,7 +204,7 @@ struct RowPack {
 
 // Block parallel cyclic reduction of S_t y_{t-h} + y_t + P_t y_{t+h} = r_t over the T lanes of group g.
 // dl_t = (S_t + I + P_t) 1 is the slack vector of the row, carried as in the scalar reduction.
-template <int K, class G>
+template <int K, bool FAST = false, class G>
 __device__ __forceinline__ Vec<K> block_pcr(const G &g, Mat<K> S, Mat<K> Pm, Vec<K> dl, Vec<K> r, int &singular) {
 #pragma unroll 1
     for (int h = 1; h < G::T; h <<= 1) {
@@ -221,7 +224,7 @@ __device__ __forceinline__ Vec<K> block_pcr(const G &g, Mat<K> S, Mat<K> Pm, Vec
         const Vec<K> d2 = sub(sub(dl, mul(S, dm)), mul(Pm, dp));
         Mat<K> Gm = sub(sub(mat_identity<K>(1.0), mul(S, Pmm)), mul(Pm, Sp));
         diag_from_rowsum(Gm, sub(sub(d2, rowsum(S2)), rowsum(P2)));
-        const Mat<K> Gi = inverse(Gm, singular);
+        const Mat<K> Gi = inverse<FAST>(Gm, singular);
         r = mul(Gi, sub(sub(r, mul(S, rm)), mul(Pm, rp)));
         S = mul(Gi, S2);
         Pm = mul(Gi, P2);
@@ -230,7 +233,8 @@ __device__ __forceinline__ Vec<K> block_pcr(const G &g, Mat<K> S, Mat<K> Pm, Vec
     return r;
 }
 
-template <int K, int P>
+// FAST: reciprocals of the determinants by recip<true> (tg_comm.h).
+template <int K, int P, bool FAST = false>
 struct BlockElim {
     Mat<K> E[P], L[P];
     Vec<K> f[P], rho[P];     // rho_i = (I + E_i + L_i) 1, the slack vector of the eliminated row
@@ -256,7 +260,7 @@ struct BlockElim {
         }
         // Den 1 = dlt - A 1 - C rho_{i-1} + C L_{i-1} 1
         diag_from_rowsum(Den, add(sub(tv, rowsum(A)), cl1));
-        const Mat<K> Di = inverse(Den, singular);
+        const Mat<K> Di = inverse<FAST>(Den, singular);
         E[i] = mul(Di, A);
         f[i] = mul(Di, rhs);
         L[i] = mul(Di, CL);
@@ -291,7 +295,7 @@ struct BlockElim {
             const Mat<K> P2 = neg(mul(El, E0));
             Mat<K> Gm = sub(mat_identity<K>(1.0), mul(El, L0));
             diag_from_rowsum(Gm, sub(sub(sig, rowsum(S2)), rowsum(P2)));
-            const Mat<K> Gi = inverse(Gm, singular);
+            const Mat<K> Gi = inverse<FAST>(Gm, singular);
             S = mul(Gi, S2);
             Pm = mul(Gi, P2);
             dl = mul(Gi, sig);
@@ -302,7 +306,7 @@ struct BlockElim {
             dl = rho[0];
             r = f[0];
         }
-        const Vec<K> y = block_pcr<K>(g, S, Pm, dl, r, singular);
+        const Vec<K> y = block_pcr<K, FAST>(g, S, Pm, dl, r, singular);
         x[P - 1] = y;
         if constexpr (P > 1) {
             double yq[K], ylq[K], yrq[K];
