@@ -366,6 +366,29 @@ def g14():
     save('g14_geometry', **out)
 
 
+def g15():
+    """Flux-model decorators (tango/extras/noisyflux.py, bufferzone.py) with numpy's global generator seeded.  The
+    reference's bufferzone calls scipy.signal.tukey, which this SciPy only has as scipy.signal.windows.tukey: the
+    window itself is recorded."""
+    import scipy.signal.windows
+    from tango.extras import noisyflux
+    out = {}
+    np.random.seed(11)
+    out['ar1_300_7p5'] = noisyflux.ar1noise(300, 7.5)
+    out['ar1_64_3'] = noisyflux.ar1noise(64, 3.0)
+    v = np.linspace(1.0, 2.0, 200) ** 2
+    out['v'] = v
+    out['dampen_default'] = noisyflux.dampen_sides(v)
+    out['dampen_10'] = noisyflux.dampen_sides(v, 10)
+    np.random.seed(12)
+    out['noisy'] = noisyflux.NoisyFlux._add_noise(v, 0.1, 7.5)
+    out['uniform'] = noisyflux.UniformNoisyFlux._add_noise(v, 0.2)
+    out['tukey_200_0p3'] = scipy.signal.windows.tukey(200, 0.3)
+    out['tukey_51_0p5'] = scipy.signal.windows.tukey(51, 0.5)
+    out['tukey_40_1'] = scipy.signal.windows.tukey(40, 1.0)
+    save('g15_decorators', **out)
+
+
 # ---------------------------------------------------------------- G9 three-field trajectories
 def run_ref_3f(N, nu0, BCs, a_turb, a_prof, tol, maxit, inner=0, dt=1e6, keep=()):
     dx = 1 / (N - 1); x = np.arange(N) * dx
@@ -457,6 +480,6 @@ def g11():
 
 
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14']
+    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15']
     for w in which:
         globals()[w]()

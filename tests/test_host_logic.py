@@ -161,3 +161,31 @@ def test_restart_file_layout(tmp_path, monkeypatch):
     tango_amd.restart.write_state(s, 'other', 0)
     with pytest.raises(ValueError):
         tango_amd.restart.check_if_should_restart()
+
+
+def test_flux_decorators_match_reference():
+    """extras.noisyflux / extras.bufferzone against the reference's output with the same seed (golden g15)."""
+    from conftest import load_golden
+    from tango_amd.extras import bufferzone, noisyflux
+    g = load_golden('g15_decorators')
+    np.random.seed(11)
+    assert np.allclose(noisyflux.ar1noise(300, 7.5), g['ar1_300_7p5'], rtol=1e-12, atol=1e-14)
+    assert np.allclose(noisyflux.ar1noise(64, 3.0), g['ar1_64_3'], rtol=1e-12, atol=1e-14)
+    v = g['v']
+    assert np.array_equal(noisyflux.dampen_sides(v), g['dampen_default'])
+    assert np.array_equal(noisyflux.dampen_sides(v, 10), g['dampen_10'])
+    np.random.seed(12)
+    assert np.allclose(noisyflux.NoisyFlux._add_noise(v, 0.1, 7.5), g['noisy'], rtol=1e-12)
+    assert np.allclose(noisyflux.UniformNoisyFlux._add_noise(v, 0.2), g['uniform'], rtol=1e-12)
+    for n, a, key in ((200, 0.3, 'tukey_200_0p3'), (51, 0.5, 'tukey_51_0p5'), (40, 1.0, 'tukey_40_1')):
+        assert np.allclose(bufferzone.tukey_window(n, a), g[key], rtol=0, atol=1e-15), key
+    assert np.allclose(bufferzone._damp_flux(v, 0.15), v * g['tukey_200_0p3'], rtol=0, atol=1e-15)
+
+    class M(object):
+        def get_flux(self, profiles):
+            return {'n': np.tile(v, (3, 1))}
+    out = bufferzone.BufferZone(M(), 0.15).get_flux({})['n']
+    assert out.shape == (3, 200) and np.allclose(out[2], v * g['tukey_200_0p3'], atol=1e-15)
+    np.random.seed(5)
+    nz = noisyflux.NoisyFlux(M(), 0.1, 0.05, 1 / 199).get_flux({})['n']
+    assert nz.shape == (3, 200) and not np.allclose(nz[0], nz[1]) and np.array_equal(nz[:, 0], v[[0, 0, 0]])
