@@ -315,10 +315,14 @@ __global__ void status_reduce_kernel(const int32_t *__restrict__ status, int64_t
 // MULTI = false compiles the single-iteration form (no loop, no selects on `done`).
 // rows can go through the coalesced path of tg_wave_io.h when a wavefront owns whole profiles, 512 points in all
 template <int P, class G, bool FULL>
-constexpr bool kWaveCoop = !G::kBlock && FULL && P == 8;
+constexpr bool kWaveCoop = FULL && P == 8 && !(G::kBlock && G::T > 512);   // 1024 threads: no LDS left for tiles
+// LDS tiles per wavefront for that path: four, or two in a workgroup-per-profile kernel, whose exchange area shares
+// the LDS (four tiles there cost a resident workgroup per CU and measured slower)
+template <class G>
+constexpr int kCoopTiles = G::kBlock ? 2 : 4;
 
 template <int P, class G, bool FULL, bool GENERAL, bool MULTI>
-__global__ void __launch_bounds__(G::kBlock ? G::T : 256, G::kBlock ? 1 : 2)   // two wavefronts per SIMD: <= 256 registers
+__global__ void __launch_bounds__(G::kBlock ? G::T : 256, (G::kBlock && G::T > 512) ? 4 : 2)   // two wavefronts per SIMD: <= 256 registers
 picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     extern __shared__ double lds[];
     G g(lds);
@@ -328,7 +332,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     // several short profiles per wavefront as long as all of them exist (not the tail of the ensemble).  Profiles
     // of such a wavefront that need no iteration stay in it as `done` from the start and take part in the I/O.
     constexpr bool COOP_T = kWaveCoop<P, G, FULL>;
-    constexpr bool COOP_ALWAYS = COOP_T && G::T == 64;
+    constexpr bool COOP_ALWAYS = COOP_T && (G::kBlock || G::T == 64);
     const bool exists = b < S_.nb;
     const bool coop = COOP_ALWAYS || (COOP_T && __all(exists));
     if (!exists) return;
@@ -357,9 +361,11 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     // the whole state of the profile, loaded once
     double u[P + 2], ue[P], um1[P], DE[P], cE[P];
     double fl[GENERAL ? P : 1];
-    const int64_t woff = off - (int64_t)((threadIdx.x & 63) / G::T) * S_.n;   // first profile of this wavefront
+    // first element of this wavefront's 512 doubles: its first profile, or its segment of the workgroup's profile
+    const int64_t woff = G::kBlock ? off + (int64_t)(threadIdx.x >> 6) * 512 : off - (int64_t)((threadIdx.x & 63) / G::T) * S_.n;
     using Tile = WaveTile<8>;
-    Tile wt(lds + (COOP_T ? (threadIdx.x >> 6) * 4 * Tile::kDoubles : 0));
+    constexpr int NT = kCoopTiles<G>;
+    Tile wt(lds + (COOP_T ? (G::kBlock ? 8 * G::T : 0) + (threadIdx.x >> 6) * NT * Tile::kDoubles : 0));
     auto load_state_coop = [&]() {
         double2 r0[4], r1[4], r2[4], r3[4], r4[4];
         wt.fetch(S_.u + woff, r0);
@@ -367,16 +373,31 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         wt.fetch(S_.DE + woff, r2);
         wt.fetch(S_.cE + woff, r3);
         wt.fetch(S_.um1 + woff, r4);
-        wt.stage(0, r0);
-        wt.stage(1, r1);
-        wt.stage(2, r2);
-        wt.stage(3, r3);
-        Tile::sync();
-        wt.take(0, u + 1);
-        wt.take(1, ue);
-        wt.take(2, DE);
-        wt.take(3, cE);
-        Tile::sync();
+        if constexpr (NT >= 4) {
+            wt.stage(0, r0);
+            wt.stage(1, r1);
+            wt.stage(2, r2);
+            wt.stage(3, r3);
+            Tile::sync();
+            wt.take(0, u + 1);
+            wt.take(1, ue);
+            wt.take(2, DE);
+            wt.take(3, cE);
+            Tile::sync();
+        } else {
+            wt.stage(0, r0);
+            wt.stage(1, r1);
+            Tile::sync();
+            wt.take(0, u + 1);
+            wt.take(1, ue);
+            Tile::sync();
+            wt.stage(0, r2);
+            wt.stage(1, r3);
+            Tile::sync();
+            wt.take(0, DE);
+            wt.take(1, cE);
+            Tile::sync();
+        }
         wt.stage(0, r4);
         Tile::sync();
         wt.take(0, um1);
@@ -638,18 +659,34 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     auto store_state_coop = [&](auto pred) {
         const bool turb = !Q.frozen_turb;
         const uint64_t amask = decltype(pred)::value ? __ballot(active) : ~0ull;   // lanes whose profile was stepped
-        wt.put(0, u + 1);
-        if (turb) {
-            wt.put(1, ue);
-            wt.put(2, DE);
-            wt.put(3, cE);
-        }
-        Tile::sync();
-        wt.template flush<decltype(pred)::value>(0, S_.u + woff, amask);
-        if (turb) {
-            if (!external) wt.template flush<decltype(pred)::value>(1, S_.uE + woff, amask);
-            wt.template flush<decltype(pred)::value>(2, S_.DE + woff, amask);
-            wt.template flush<decltype(pred)::value>(3, S_.cE + woff, amask);
+        if constexpr (NT >= 4) {
+            wt.put(0, u + 1);
+            if (turb) {
+                wt.put(1, ue);
+                wt.put(2, DE);
+                wt.put(3, cE);
+            }
+            Tile::sync();
+            wt.template flush<decltype(pred)::value>(0, S_.u + woff, amask);
+            if (turb) {
+                if (!external) wt.template flush<decltype(pred)::value>(1, S_.uE + woff, amask);
+                wt.template flush<decltype(pred)::value>(2, S_.DE + woff, amask);
+                wt.template flush<decltype(pred)::value>(3, S_.cE + woff, amask);
+            }
+        } else {
+            wt.put(0, u + 1);
+            if (turb) wt.put(1, ue);
+            Tile::sync();
+            wt.template flush<decltype(pred)::value>(0, S_.u + woff, amask);
+            if (turb) {
+                if (!external) wt.template flush<decltype(pred)::value>(1, S_.uE + woff, amask);
+                Tile::sync();
+                wt.put(0, DE);
+                wt.put(1, cE);
+                Tile::sync();
+                wt.template flush<decltype(pred)::value>(0, S_.DE + woff, amask);
+                wt.template flush<decltype(pred)::value>(1, S_.cE + woff, amask);
+            }
         }
     };
     auto store_state_lane = [&]() {
@@ -732,7 +769,7 @@ struct Picard1fLauncher {
         const bool full = (n == P * G::T) && (al & 15) == 0;
         const bool general = q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly;
         const bool multi = q->iters_per_launch > 1;
-        if (kWaveCoop<P, G, true> && full) lds = (size_t)(block / 64) * 4 * WaveTile<8>::kDoubles * sizeof(double);
+        if (kWaveCoop<P, G, true> && full) lds += (size_t)(block / 64) * kCoopTiles<G> * WaveTile<8>::kDoubles * sizeof(double);
 #define TG_LAUNCH_1F(F, GEN, M) hipLaunchKernelGGL((picard_1f_kernel<P, G, F, GEN, M>), dim3(grid), dim3(block), lds, s, *st, *q)
         if (general) {
             if (full) TG_LAUNCH_1F(true, true, true);

@@ -17,9 +17,11 @@
 namespace tg {
 
 // x / d, either as the division itself (EXACT) or as x * (1/d) with the reciprocal formed once
+// (The EXACT quotient is quot<true> of tg_comm.h: the arithmetic of the IEEE division sequence, bit for bit, for
+// operands in the normal range, at two thirds of its issue slots.)
 template <bool EXACT>
 __device__ __forceinline__ double cdiv(double x, double d, double inv) {
-    if constexpr (EXACT) return x / d;
+    if constexpr (EXACT) return quot<true>(x, d);
     else return x * inv;
 }
 
@@ -109,7 +111,7 @@ template <bool EXACT>
 __device__ __forceinline__ double ddx_edge1_point(double um, double u0, double up, bool first, bool last,
                                                   const Recip &rc) {
     const double num = first ? (up - u0) : (last ? (u0 - um) : (up - um));
-    if constexpr (EXACT) return num / ((first || last) ? rc.dx : rc.twodx);
+    if constexpr (EXACT) return quot<true>(num, (first || last) ? rc.dx : rc.twodx);
     else return num * ((first || last) ? rc.idx : rc.i2dx);
 }
 

@@ -156,7 +156,7 @@ def test_ensemble32_matches_reference(tango, golden):
     assert same >= 24      # the great majority stop on the reference's iteration
 
 
-@pytest.mark.parametrize('N', [40, 100, 300, 1000, 2048])
+@pytest.mark.parametrize('N', [40, 100, 300, 1000, 1024, 2048, 4096])
 def test_fused_step_other_sizes_vs_oracle(tango, N):
     """Ragged sizes (not a multiple of the 8-point lane chunk) and the multi-wavefront path (N > 512)."""
     from tango_amd.ensemble import OneFieldEnsemble
@@ -166,7 +166,7 @@ def test_fused_step_other_sizes_vs_oracle(tango, N):
     for _ in range(its):
         E.step()
     H7 = orc.shestakov_source(ens['x'], ens['S0'], ens['delta'])
-    bar = TOL if N <= 1024 else 3e-10     # conditioning grows as N^2 (cond ~1e9 at N=2048)
+    bar = TOL if N <= 1024 else (3e-10 if N <= 2048 else 1e-9)     # conditioning grows as N^2 (cond ~1e9 at N=2048)
     for b in range(nb):
         st = orc.State1F(ens['u0'][b])
         for _ in range(its):
