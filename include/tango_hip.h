@@ -182,10 +182,20 @@ typedef struct {
     int32_t reserved_;
     double tread_max_change;
     double tread_initial_dtau;
+    /* Optional work space of tg_picard_1f_work_bytes(nb, n) bytes.  With it, profiles of more than 4096 points
+     * (n a multiple of 512, built-in flux, Cartesian, one iteration per call) are stepped in segments of 512 points,
+     * one wavefront each, in three kernels: turbulence update + assembly + elimination per segment; the reduced
+     * system of the segment-lane unknowns per profile; back substitution per segment.  Without it (NULL) such
+     * profiles take the one-workgroup-per-profile kernel, which is 2-4 times slower at those sizes. */
+    void *work;
+    size_t work_bytes;
 } tg_params_1f;
 
 enum { TG_TREAD_MAX_HALVINGS = 64 };
 
+/* bytes of tg_params_1f.work that make the segmented form available for (nb, n); 0 where it does not apply
+ * (tango/solver.py:188-272 has no counterpart of a work space: NumPy allocates its temporaries itself) */
+size_t tg_picard_1f_work_bytes(int64_t nb, int64_t n);
 int tg_picard_1f_step(const tg_state_1f *state, const tg_params_1f *params, tg_stream stream);
 
 /* counts[0..3] (device int64): profiles still active, converged, invalid, singular;

@@ -24,7 +24,7 @@ class HipError(RuntimeError):
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
-        f'{LIB_PATH} is missing: build it with `python -m tango_amd.build` (hipcc, gfx950). '
+        f'{LIB_PATH} is missing: build it with `python tango_amd/build.py` (hipcc, gfx950). '
         'tango_amd has no CPU fallback.')
 
 lib = C.CDLL(LIB_PATH)
@@ -54,7 +54,7 @@ class Params1F(C.Structure):
                 ('smooth_window', C.c_int32), ('fixed_count', C.c_int32), ('frozen_turb', C.c_int32),
                 ('iters_per_launch', C.c_int32), ('pseudo_time', C.c_int32), ('tread_lightly', C.c_int32),
                 ('tread_inner_count', C.c_int32), ('tread_initial_steps', C.c_int32), ('reserved_', C.c_int32),
-                ('tread_max_change', _dbl), ('tread_initial_dtau', _dbl)]
+                ('tread_max_change', _dbl), ('tread_initial_dtau', _dbl), ('work', _p), ('work_bytes', _sz)]
 
 
 class State3F(C.Structure):
@@ -85,6 +85,7 @@ PROTOTYPES = {
     'tg_stream_sync': (_int, [_p]),
     'tg_stream_probe': (_int, [_p * 5, _p * 4, _i64, _p]),
     'tg_tridiag_work_bytes': (_sz, [_i64, _i64, _int]),
+    'tg_picard_1f_work_bytes': (_sz, [_i64, _i64]),
     'tg_tridiag_solve': (_int, [_p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _sz, _p]),
     'tg_h_to_matrix': (_int, [_dbl, _p, _dbl, _p, _p, C.POINTER(HCoeffsC), _p, _p, _p, _p, _p, _i64, _i64, _p]),
     'tg_residual': (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p]),

@@ -1,6 +1,6 @@
 """Build libtango_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python -m tango_amd.build [--report]
+    python tango_amd/build.py [--report]      (run as a script: importing the package needs the built library)
 
 The library is written in-tree to tango_amd/lib/ so that it travels with the source tree."""
 import os
@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, 'csrc', f) for f in ('tango_hip.hip', 'tango_block.hip')]
+SRC = [os.path.join(HERE, 'csrc', f) for f in ('tango_hip.hip', 'tango_block.hip', 'tango_seg.hip')]
 OUT = os.path.join(HERE, 'lib', 'libtango_hip.so')
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-Wall', '-Wno-format-security',
          '-Wno-unused-function']

@@ -919,6 +919,8 @@ int tg_shestakov_flux(const double *nprof, double dx, double *flux, int64_t nb, 
     return launch_check();
 }
 
+size_t tg_picard_1f_work_bytes(int64_t nb, int64_t n) { return (nb > 0 && n > 0) ? tg_seg_work_bytes(nb, n) : 0; }
+
 int tg_picard_1f_step(const tg_state_1f *st, const tg_params_1f *q, tg_stream stream) {
     if (!st || !q) return fail(TG_ERR_ARG, "NULL state or params%s");
     if (int e = check_dims(st->nb, st->n, 3)) return e;
@@ -936,6 +938,7 @@ int tg_picard_1f_step(const tg_state_1f *st, const tg_params_1f *q, tg_stream st
     if (q->smooth_window > 1) return fail(TG_ERR_UNSUPPORTED, "flux smoothing is not fused; smooth the flux with tg_moving_average and pass it as an external flux%s");
     if (st->err && st->err_stride <= 0) return fail(TG_ERR_ARG, "err_stride must be positive%s");
     if (st->nb == 0) return TG_OK;
+    if (tg_seg_applies(st, q)) return tg_seg_step(st, q, S(stream));
     return dispatch_group<Picard1fLauncher, true>(st->nb, (int)st->n, S(stream), st, q);
 }
 

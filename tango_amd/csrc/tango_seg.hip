@@ -1,0 +1,442 @@
+// Segmented form of the fused one-field Picard iteration for long profiles (n = S x 512, S > 8).
+//
+// A workgroup per profile runs out of registers beyond 4096 points (one resident workgroup per CU, its load,
+// compute and store phases serialised).  Here every 512-point segment is one wavefront, exactly as a whole profile
+// of up to 512 points is in picard_1f_kernel, and the coupling between segments is resolved at the level the
+// chunked elimination already works on: every lane eliminates its 8 rows down to one row in the lanes' last
+// unknowns y; those n/8 rows form one tridiagonal system per profile, whatever segment a lane belongs to.
+//
+//   halo    (one thread per segment boundary): the EWMA memories next to the boundary are copied aside
+//   phase 0 (one wavefront per segment): EWMA -> flux -> split -> EWMA (stored), assembly, residual partial sums,
+//            elimination of the lane's rows; the lane's last-row and first-row forms go to the work space
+//   reduce  (one workgroup per profile): the reduced rows are formed and solved (same chunked elimination + PCR,
+//            slack carried through), y goes to the work space; residual norm, convergence decision
+//   phase 1 (one wavefront per segment): assembly and elimination again (three arrays are read instead of keeping
+//            24 bytes per point of multipliers), back substitution from y, validity check, new profile stored
+//
+// Tango reference: tango/solver.py:188-272 on tango/lodestro_method.py:327-408, tango/HToMatrixFD.py:53-117,
+// tango/tridiag.py:12-31, as for picard_1f_kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tango_hip.h"
+#include "tg_assemble.h"
+#include "tg_comm.h"
+#include "tg_host.h"
+#include "tg_io.h"
+#include "tg_solve.h"
+#include "tg_wave_io.h"
+
+namespace {
+
+using namespace tg;
+
+constexpr int kSeg = 512;        // points per segment = 64 lanes x 8 points
+constexpr int kRowQ = 7;         // doubles a lane leaves for the reduced system
+
+// work space layout (all double unless noted), L = nb n / 8 lanes, S = n / 512 segments per profile
+struct SegWork {
+    double *row[kRowQ];   // el, ll, fl, rl (last-row form), F, E, tau (first-row form), each (L,)
+    double *y;            // (L,) lane-last unknowns
+    double *ss, *mx;      // (nb S,) residual partial sums and max |f| per segment
+    double *halo;         // (nb (S-1), 8) EWMA memories at the four points around every segment boundary, copied before
+                          // phase 0 overwrites them: uE(j-2), uE(j-1), uE(j), uE(j+1), DE(j-1), DE(j), cE(j-1), cE(j), j = 512 (k+1)
+    int32_t *flag;        // (nb,) 0: not stepped in this call, 1: stepped, 2: stepped and converged
+    int32_t *sing;        // (nb,) zero pivot met somewhere
+};
+
+size_t seg_work_bytes(int64_t nb, int64_t n) {
+    const int64_t L = nb * n / 8, S = n / kSeg;
+    size_t b = sizeof(double) * (size_t)((kRowQ + 1) * L + 2 * nb * S + 8 * nb * (S - 1)) + sizeof(int32_t) * (size_t)(2 * nb);
+    return (b + 255) & ~(size_t)255;
+}
+
+SegWork seg_carve(void *work, int64_t nb, int64_t n) {
+    const int64_t L = nb * n / 8, S = n / kSeg;
+    SegWork W;
+    double *p = static_cast<double *>(work);
+    for (int k = 0; k < kRowQ; ++k, p += L) W.row[k] = p;
+    W.y = p; p += L;
+    W.ss = p; p += nb * S;
+    W.mx = p; p += nb * S;
+    W.halo = p; p += 8 * nb * (S - 1);
+    W.flag = reinterpret_cast<int32_t *>(p);
+    W.sing = W.flag + nb;
+    return W;
+}
+
+// ------------------------------------------------------------------------------------------
+// Phase 0 replaces uE, DE and cE in place while neighbouring segments still need the old values next to their
+// boundaries: those are copied aside first (one thread per boundary).
+// ------------------------------------------------------------------------------------------
+__global__ void seg_halo_kernel(tg_state_1f S_, SegWork W) {
+    const int S = (int)(S_.n / kSeg);
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S_.nb * (S - 1)) return;
+    const int64_t b = k / (S - 1);
+    const int64_t j = b * S_.n + (int64_t)((k - b * (S - 1)) + 1) * kSeg;
+    double *h = W.halo + 8 * k;
+    h[0] = S_.uE[j - 2];
+    h[1] = S_.uE[j - 1];
+    h[2] = S_.uE[j];
+    h[3] = S_.uE[j + 1];
+    h[4] = S_.DE[j - 1];
+    h[5] = S_.DE[j];
+    h[6] = S_.cE[j - 1];
+    h[7] = S_.cE[j];
+}
+
+// ------------------------------------------------------------------------------------------
+// phases 0 and 1: one wavefront per segment
+// ------------------------------------------------------------------------------------------
+template <int PHASE>
+__global__ void __launch_bounds__(256, 2)
+picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
+    extern __shared__ double lds[];
+    using G = WaveGroup<64>;
+    constexpr int P = 8;
+    constexpr bool EXACT = true;      // these grids have condition numbers above 1e9: the reference's quotients
+    G g(lds);
+    const int n = (int)S_.n;
+    const int S = n / kSeg;
+    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // segment index over the ensemble
+    if (w >= S_.nb * S) return;
+    const int64_t b = w / S;
+    const int s = (int)(w - b * S);
+    const int st = S_.status[b];
+    if (PHASE == 0) {
+        if (!Q.fixed_count && (st & (TG_ST_CONVERGED | TG_ST_INVALID))) return;
+    } else {
+        if (W.flag[b] == 0) return;
+    }
+    const int t = g.t();
+    const int j0 = s * kSeg + t * P;                 // first point of this lane within the profile
+    const int64_t off = b * S_.n;
+    const int64_t woff = off + (int64_t)s * kSeg;
+    const int64_t lane_id = (b * S_.n + (int64_t)s * kSeg) / P + t;   // index of this lane among all lanes
+    const bool first_lane = (s == 0 && t == 0);      // holds the first point of the profile
+    const bool last_lane = (s == S - 1 && t == 63);  // holds the last point of the profile (Dirichlet row)
+    const Recip rc(Q.dx, Q.dt_b ? Q.dt_b[b] : Q.dt);
+    const double UL = Q.UL[b];
+    const double S0 = Q.H7 ? 0.0 : Q.S0[b];
+    const int src_cut = Q.H7 ? 0 : Q.src_cut[b];
+    const Theta th(Q.Dmin, Q.Dmax, Q.dpdx_thr);
+    const double omp = 1.0 - Q.a_prof, omt = 1.0 - Q.a_turb;
+    const bool seeded = (st & TG_ST_SEEDED) != 0;
+    const bool turb = !Q.frozen_turb;
+
+    using Tile = WaveTile<8>;
+    Tile wt(lds + (threadIdx.x >> 6) * 4 * Tile::kDoubles);
+
+    double u[P + 2], um1[P], DE[P], cE[P];
+    // values at the point just outside this wavefront's segment, on the side of this lane if it is lane 0 or 63
+    // (nothing there for the two ends of the profile): new EWMA profile, H2, H3, current profile
+    const bool edge_l = (t == 0 && s > 0), edge_r = (t == 63 && s < S - 1);
+    const int jh = edge_l ? j0 - 1 : j0 + P;         // the halo point of an edge lane
+    double h_ue = 0.0, h_D = 0.0, h_c = 0.0, h_u = 0.0;
+
+    if (PHASE == 0) {
+        double ue[P];
+        double2 r0[4], r1[4], r2[4], r3[4], r4[4];
+        wt.fetch(S_.u + woff, r0);
+        wt.fetch(S_.uE + woff, r1);
+        wt.fetch(S_.DE + woff, r2);
+        wt.fetch(S_.cE + woff, r3);
+        wt.fetch(S_.um1 + woff, r4);
+        // the neighbouring segment's two nearest points, for the edge lanes: its new iterates are recomputed here
+        double n_u0 = 0.0, n_u1 = 0.0, n_e0 = 0.0, n_e1 = 0.0, n_D = 0.0, n_c = 0.0;   // index 0: the halo point, 1: one further out
+        if (edge_l || edge_r) {
+            const int j1 = edge_l ? jh - 1 : jh + 1;
+            n_u0 = S_.u[off + jh];       // u changes in phase 1 only
+            n_u1 = S_.u[off + j1];
+            const double *h = W.halo + 8 * (b * (S - 1) + (edge_l ? s - 1 : s));
+            n_e0 = edge_l ? h[1] : h[2];
+            n_e1 = edge_l ? h[0] : h[3];
+            n_D = edge_l ? h[4] : h[5];
+            n_c = edge_l ? h[6] : h[7];
+        }
+        wt.stage(0, r0);
+        wt.stage(1, r1);
+        wt.stage(2, r2);
+        wt.stage(3, r3);
+        Tile::sync();
+        wt.take(0, u + 1);
+        wt.take(1, ue);
+        wt.take(2, DE);
+        wt.take(3, cE);
+        Tile::sync();
+        wt.stage(0, r4);
+        Tile::sync();
+        wt.take(0, um1);
+        Tile::sync();
+
+        auto split = [&](double pm, double p, double pp, bool first, bool last, double &D, double &c) {
+            const double dpdx = ddx_edge1_point<EXACT>(pm, p, pp, first, last, rc);
+            const double flux = -(dpdx * dpdx * dpdx) / (p * p);   // tango/extras/shestakov_nonlinear_diffusion.py:59-60
+            double DH, cH, thv;
+            flux_split_point(flux, p, dpdx, 1.0, 1.0, th, D, c, DH, cH, thv);
+        };
+        if (turb) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) ue[i] = Q.a_prof * u[i + 1] + omp * (seeded ? ue[i] : u[i + 1]);
+            const double e0 = Q.a_prof * n_u0 + omp * (seeded ? n_e0 : n_u0);
+            const double e1 = Q.a_prof * n_u1 + omp * (seeded ? n_e1 : n_u1);
+            h_ue = e0;
+            // D and c at the halo point, from the new EWMA profile on both of its sides
+            {
+                double D, c;
+                split(edge_l ? e1 : ue[P - 1], e0, edge_l ? ue[0] : e1, false, false, D, c);
+                h_D = Q.a_turb * D + omt * (seeded ? n_D : D);
+                h_c = Q.a_turb * c + omt * (seeded ? n_c : c);
+            }
+            double wl = g.from_left(ue[P - 1], 1, 0.0);
+            double wr = g.from_right(ue[0], 1, 0.0);
+            wl = edge_l ? h_ue : wl;
+            wr = edge_r ? h_ue : wr;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const bool first = (i == 0) && first_lane;
+                const bool last = (i == P - 1) && last_lane;
+                const double pm = (i == 0) ? wl : ue[i > 0 ? i - 1 : 0];
+                const double pp = (i == P - 1) ? wr : ue[i < P - 1 ? i + 1 : 0];
+                double D, c;
+                split(pm, ue[i], pp, first, last, D, c);
+                DE[i] = Q.a_turb * D + omt * (seeded ? DE[i] : D);
+                cE[i] = Q.a_turb * c + omt * (seeded ? cE[i] : c);
+            }
+            wt.put(1, ue);
+            wt.put(2, DE);
+            wt.put(3, cE);
+            Tile::sync();
+            wt.flush(1, S_.uE + woff);
+            wt.flush(2, S_.DE + woff);
+            wt.flush(3, S_.cE + woff);
+        } else {
+            h_D = n_D;
+            h_c = n_c;
+        }
+        h_u = n_u0;
+    } else {
+        double2 r2[4], r3[4], r4[4];
+        wt.fetch(S_.DE + woff, r2);
+        wt.fetch(S_.cE + woff, r3);
+        wt.fetch(S_.um1 + woff, r4);
+        if (edge_l || edge_r) {
+            h_D = S_.DE[off + jh];
+            h_c = S_.cE[off + jh];
+        }
+        wt.stage(0, r2);
+        wt.stage(1, r3);
+        wt.stage(2, r4);
+        Tile::sync();
+        wt.take(0, DE);
+        wt.take(1, cE);
+        wt.take(2, um1);
+        Tile::sync();
+    }
+
+    // H2 = D, H3 = -c of the neighbouring lanes' nearest points; across a segment boundary the halo point's
+    // (every lane takes part in the shuffles; the edge lanes then substitute their halo values)
+    const double s2l = g.from_left(DE[P - 1], 1, 0.0), s3l = g.from_left(-cE[P - 1], 1, 0.0);
+    const double s2r = g.from_right(DE[0], 1, 0.0), s3r = g.from_right(-cE[0], 1, 0.0);
+    const double h2l = edge_l ? h_D : s2l;
+    const double h3l = edge_l ? -h_c : s3l;
+    const double h2r = edge_r ? h_D : s2r;
+    const double h3r = edge_r ? -h_c : s3r;
+    if (PHASE == 0) {
+        const double ul = g.from_left(u[P], 1, 0.0), ur = g.from_right(u[1], 1, 0.0);
+        u[0] = edge_l ? h_u : ul;
+        u[P + 1] = edge_r ? h_u : ur;
+    }
+
+    // assemble and eliminate (tango/HToMatrixFD.py:87-117 row by row, as in picard_1f_kernel)
+    ChunkElim<P, false> el;
+    double hm2 = first_lane ? 0.0 : (h2l + DE[0]) / 2.0;
+    double hm3 = first_lane ? 0.0 : (h3l - cE[0]) / 2.0;
+    double bm = fbeta_point<false>(hm2, hm3, rc.dx);
+    double mx = 0.0, ss = 0.0;
+    double h2c = DE[0], h3c = -cE[0];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int j = j0 + i;
+        const bool last = (i == P - 1) && last_lane;
+        const double h2n = (i == P - 1) ? h2r : DE[i < P - 1 ? i + 1 : 0];
+        const double h3n = (i == P - 1) ? h3r : -cE[i < P - 1 ? i + 1 : 0];
+        const double hp2 = (h2c + h2n) / 2.0;
+        const double hp3 = (h3c + h3n) / 2.0;
+        const double bp = fbeta_point<false>(hp2, hp3, rc.dx);
+        const double H1 = Q.H1 ? Q.H1[j] : 1.0;
+        const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + j] : ((j < src_cut) ? S0 : 0.0);
+        double A, B, C, f;
+        fd_row<EXACT>(last, H1, um1[i], rc, UL, hm2, hm3, bm, hp2, hp3, bp, 0.0, 0.0, h7, A, B, C, f);
+        if (PHASE == 0) {
+            // residual of the current profile with the new matrix (tango/fieldgroups.py:139); zero-padded shifts
+            // at the two ends of the profile
+            const double r = A * u[i + 2] + B * u[i + 1] + C * u[i] - f;
+            ss += r * r;
+            mx = fmax(mx, fabs(f));
+        }
+        el.push(i, C, B, A, f);
+        hm2 = hp2;
+        hm3 = hp3;
+        bm = bp;
+        h2c = h2n;
+        h3c = h3n;
+    }
+
+    if (PHASE == 0) {
+        // what the reduced system needs from this lane: its last row x_last + e x_next = f - l y_left with slack rho,
+        // and its first unknown x_0 = F - L y_left - E y with slack tau (ChunkElim::finish forms the same values)
+        double F = el.f[P - 2], L = el.l[P - 2], E = el.e[P - 2], tau = el.rho[P - 2];
+#pragma unroll
+        for (int i = P - 3; i >= 0; --i) {
+            F = el.f[i] - el.e[i] * F;
+            L = el.l[i] - el.e[i] * L;
+            tau = el.rho[i] - el.e[i] * tau;
+            E = -el.e[i] * E;
+        }
+        (void)L;
+        W.row[0][lane_id] = el.e[P - 1];
+        W.row[1][lane_id] = el.l[P - 1];
+        W.row[2][lane_id] = el.f[P - 1];
+        W.row[3][lane_id] = el.rho[P - 1];
+        W.row[4][lane_id] = F;
+        W.row[5][lane_id] = E;
+        W.row[6][lane_id] = tau;
+        mx = g.max(mx);
+        ss = g.sum(ss);
+        const int sing = g.any(el.singular);
+        if (t == 0) {
+            W.ss[b * S + s] = ss;
+            W.mx[b * S + s] = mx;
+            if (sing) atomicOr(&W.sing[b], 1);
+        }
+    } else {
+        // back substitution with this lane's last unknown y and its left neighbour's (any segment)
+        const double y = W.y[lane_id];
+        const double yl = first_lane ? 0.0 : W.y[lane_id - 1];
+        double x[P];
+        x[P - 1] = y;
+#pragma unroll
+        for (int i = P - 2; i >= 0; --i) x[i] = (el.f[i] - el.l[i] * yl) - el.e[i] * x[i + 1];
+        int bad = 0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) bad |= !(isfinite(x[i]) && x[i] >= 0.0);
+        bad = g.any(bad);
+        wt.put(0, x);
+        Tile::sync();
+        wt.flush(0, S_.u + woff);
+        if (t == 0) {
+            int bits = bad ? TG_ST_INVALID : 0;
+            if (s == 0) {
+                S_.iters[b] += 1;
+                if (turb) bits |= TG_ST_SEEDED;
+                if (W.flag[b] == 2) bits |= TG_ST_CONVERGED;
+                if (W.sing[b]) bits |= TG_ST_SINGULAR;
+            }
+            if (bits) atomicOr(&S_.status[b], bits);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the reduced system of one profile: n/8 rows, one workgroup of n/64 threads with 8 rows each
+// ------------------------------------------------------------------------------------------
+template <class G>
+__global__ void __launch_bounds__(G::T)
+picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
+    extern __shared__ double lds[];
+    constexpr int P = 8;
+    G g(lds);
+    const int64_t b = blockIdx.x;
+    const int n = (int)S_.n;
+    const int S = n / kSeg;
+    const int rows = n / 8;
+    const int st = S_.status[b];
+    const bool active = Q.fixed_count || !(st & (TG_ST_CONVERGED | TG_ST_INVALID));
+    if (!active) {
+        if (g.t() == 0) W.flag[b] = 0;
+        return;
+    }
+    const int t = g.t();
+    const int64_t base = b * rows;
+    ChunkElim<P, false> el;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int r = t * P + i;
+        const int64_t k = base + r;
+        const double e = W.row[0][k], l = W.row[1][k], f = W.row[2][k], rho = W.row[3][k];
+        // first-row form of the lane to the right; an identity row past the end of the profile
+        const bool more = r + 1 < rows;
+        const double F0 = more ? W.row[4][k + 1] : 0.0;
+        const double E0 = more ? W.row[5][k + 1] : 0.0;
+        const double T0 = more ? W.row[6][k + 1] : 1.0;
+        // l y_{r-1} + (1 - e L0) y_r - e E0 y_{r+1} = f - e F0 with slack rho - e T0, the diagonal formed from the
+        // slack (all terms of one sign for an M-matrix), as in ChunkElim::finish
+        const double sig = rho - e * T0;
+        const double s2 = l;
+        const double p2 = -(e * E0);
+        const double d = sig - s2 - p2;
+        el.push_slack(i, s2, d, p2, f - e * F0, sig);
+    }
+    double y[P];
+    el.finish(g, y);
+#pragma unroll
+    for (int i = 0; i < P; ++i) W.y[base + t * P + i] = y[i];
+    const int sing = g.any(el.singular);
+
+    // residual norm of the profile from the segments' partial sums (tango/fieldgroups.py:140, tango/solver.py:464-470)
+    if (t == 0) {
+        double ss = 0.0, mx = 0.0;
+        for (int s = 0; s < S; ++s) {
+            ss += W.ss[b * S + s];
+            mx = fmax(mx, W.mx[b * S + s]);
+        }
+        const double rms = sqrt(1.0 / (double)n * (ss / (mx * mx)));
+        const int it0 = S_.iters[b];
+        if (S_.err && it0 < S_.err_stride) S_.err[b * S_.err_stride + it0] = rms;
+        W.flag[b] = (!Q.fixed_count && rms < Q.tol) ? 2 : 1;
+        if (sing) W.sing[b] = 1;
+    }
+}
+
+}  // namespace
+
+// entry points for tango_hip.hip (C++ linkage: not part of the C ABI)
+size_t tg_seg_work_bytes(int64_t nb, int64_t n) {
+    if (n != 8192 && n != 16384 && n != 32768) return 0;      // n/64 threads solve the reduced system: a power of two
+    return seg_work_bytes(nb, n);
+}
+
+bool tg_seg_applies(const tg_state_1f *st, const tg_params_1f *q) {
+    if (!q->work || tg_seg_work_bytes(st->nb, st->n) == 0 || q->work_bytes < tg_seg_work_bytes(st->nb, st->n)) return false;
+    if (q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly ||
+        q->iters_per_launch > 1 || q->smooth_window > 1)
+        return false;
+    uintptr_t al = reinterpret_cast<uintptr_t>(st->u) | reinterpret_cast<uintptr_t>(st->um1) | reinterpret_cast<uintptr_t>(st->uE) |
+                   reinterpret_cast<uintptr_t>(st->DE) | reinterpret_cast<uintptr_t>(st->cE) | reinterpret_cast<uintptr_t>(q->work);
+    return (al & 15) == 0;
+}
+
+int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
+    const int64_t nb = st->nb;
+    const int n = (int)st->n;
+    SegWork W = seg_carve(q->work, nb, n);
+    TG_HIP(hipMemsetAsync(W.sing, 0, sizeof(int32_t) * (size_t)nb, s));
+    const int64_t segs = nb * (n / kSeg);
+    const unsigned grid = (unsigned)((segs + 3) / 4);
+    const size_t lds = 4 * 4 * WaveTile<8>::kDoubles * sizeof(double);
+    const int64_t bounds = nb * (n / kSeg - 1);
+    hipLaunchKernelGGL(seg_halo_kernel, dim3((unsigned)((bounds + 255) / 256)), dim3(256), 0, s, *st, W);
+    hipLaunchKernelGGL((picard_seg_kernel<0>), dim3(grid), dim3(256), lds, s, *st, *q, W);
+    const int lanes = n / 64;      // threads of the reduce kernel: 8 reduced rows each
+    const size_t lds_r = sizeof(double) * 8 * (size_t)lanes;
+    switch (lanes) {
+    case 128: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<128>>), dim3((unsigned)nb), dim3(128), lds_r, s, *st, *q, W); break;
+    case 256: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<256>>), dim3((unsigned)nb), dim3(256), lds_r, s, *st, *q, W); break;
+    case 512: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<512>>), dim3((unsigned)nb), dim3(512), lds_r, s, *st, *q, W); break;
+    default: return fail(TG_ERR_UNSUPPORTED, "segmented form: n must be 8192, 16384 or 32768%s");
+    }
+    hipLaunchKernelGGL((picard_seg_kernel<1>), dim3(grid), dim3(256), lds, s, *st, *q, W);
+    return launch_check();
+}

@@ -33,8 +33,11 @@ struct ChunkElim {
     // den = dlt - a - c rho_{i-1} + c l_{i-1} (= b - c e_{i-1}).  For an M-matrix every term of these sums
     // is non-negative, so the small slack (1/dt against 1/dx^2 entries) is not lost to cancellation; for any
     // other matrix the expressions are the same numbers written differently.
-    __device__ __forceinline__ void push(int i, double c, double b, double a, double d) {
-        const double dlt = (b + a) + c;
+    __device__ __forceinline__ void push(int i, double c, double b, double a, double d) { push_slack(i, c, b, a, d, (b + a) + c); }
+
+    // the same with the row's slack dlt = a + b + c supplied by the caller (rows whose slack is known more
+    // accurately than their coefficients give it, e.g. the rows of a reduced system)
+    __device__ __forceinline__ void push_slack(int i, double c, double b, double a, double d, double dlt) {
         const double fp = (i == 0) ? 0.0 : f[i > 0 ? i - 1 : 0];
         const double lp = (i == 0) ? -1.0 : l[i > 0 ? i - 1 : 0];
         const double rp = (i == 0) ? 0.0 : rho[i > 0 ? i - 1 : 0];

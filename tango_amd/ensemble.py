@@ -128,13 +128,17 @@ class OneFieldEnsemble:
     data_ptr() lets a caller own the memory (bench.py passes a torch allocator); default: tg_malloc."""
 
     def __init__(self, ens, dt=1e4, a_turb=0.3, a_prof=1.0, tol=1e-11, theta=THETA_DEFAULT, max_iter=1000,
-                 fixed_count=False, keep_err=True, alloc=None):
+                 fixed_count=False, keep_err=True, alloc=None, segmented=True):
         u0 = np.ascontiguousarray(ens['u0'], dtype=np.float64)
         self.nb, self.n = nb, n = u0.shape
         f8, i4, i8 = np.float64, np.int32, np.int64
         plan = [((nb, n), f8)] * 5 + [((nb,), i4)] * 3 + [((nb,), f8)] * 2 + [((4,), i8)]
         if keep_err:
             plan.append(((nb, max_iter), f8))
+        # work space of the segmented form of the step (profiles of 8192 points and more), 0 bytes otherwise
+        work_bytes = int(H.lib.tg_picard_1f_work_bytes(nb, n)) if segmented else 0
+        if work_bytes:
+            plan.append(((work_bytes // 8,), f8))
         self.pool = pool = Pool(Pool.size_for(plan), alloc)
         self.u, self.um1, self.uE, self.DE, self.cE = (pool.take((nb, n)) for _ in range(5))
         self.status, self.iters = pool.take((nb,), i4), pool.take((nb,), i4)
@@ -142,6 +146,7 @@ class OneFieldEnsemble:
         self.src_cut = pool.take((nb,), i4)
         self.counts = pool.take((4,), i8)
         self.err = pool.take((nb, max_iter)) if keep_err else None
+        self.work = pool.take((work_bytes // 8,)) if work_bytes else None
         self.u.set(u0)
         self.um1.set(u0)
         for v in (self.uE, self.DE, self.cE, self.status, self.iters, self.counts) + ((self.err,) if keep_err else ()):
@@ -158,6 +163,8 @@ class OneFieldEnsemble:
         q.Dmin, q.Dmax, q.dpdx_thr, q.tol = float(theta['Dmin']), float(theta['Dmax']), float(theta['dpdxThreshold']), float(tol)
         q.UL, q.S0, q.src_cut = p(self.UL), p(self.S0), p(self.src_cut)
         q.flux_model, q.smooth_window, q.fixed_count, q.frozen_turb = H.FLUX_SHESTAKOV, 1, int(fixed_count), 0
+        if self.work is not None:
+            q.work, q.work_bytes = p(self.work), work_bytes
         self.params = q
         self.max_iter = max_iter
 

@@ -447,6 +447,8 @@ class _Fused1F(object):
             self.status.set(np.full((nb,), H.ST_SEEDED, np.int32))
         self.state = H.State1F(nb, self.n, self.u.ptr, self.um1.ptr, self.uE.ptr, self.DE.ptr, self.cE.ptr,
                                self.status.ptr, self.iters.ptr, self.err.ptr, s.maxIterations)
+        wb = int(H.lib.tg_picard_1f_work_bytes(nb, self.n))      # segmented form of the step for long profiles
+        self.work = H.DeviceArray((wb // 8,)) if wb else None
 
     def params(self, s):
         m = s.fields[0].lodestroMethod
@@ -457,6 +459,8 @@ class _Fused1F(object):
         q.Dmin, q.Dmax, q.dpdx_thr, q.tol = float(tp['Dmin']), float(tp['Dmax']), float(tp['dpdxThreshold']), float(s.tol)
         ptr = lambda a: a.ptr if a is not None else None
         q.UL, q.S0, q.src_cut = self.UL.ptr, ptr(self.S0), ptr(self.src_cut)
+        if getattr(self, 'work', None) is not None:
+            q.work, q.work_bytes = self.work.ptr, self.work.nbytes
         q.flux_model, q.smooth_window, q.fixed_count, q.frozen_turb = H.FLUX_SHESTAKOV, 1, 0, 0
         # pseudo-timestep control (tango/solver.py:198-216, 311-372) runs inside the kernel
         q.pseudo_time = int(bool(s.useTreadLightly or s.useTreadInitially))

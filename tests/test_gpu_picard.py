@@ -508,3 +508,27 @@ def test_python_flux_model_ensemble(tango, golden):
             assert relerr(s.profiles['n'][b], st.u) < TOL, b
             assert relerr(lm._EWMAProfile._yEWMA_lminus1[b], st.uE) < TOL, b
     assert len(set(its)) > 1
+
+
+@pytest.mark.parametrize('N,nb', [(8192, 3), (16384, 2)])
+def test_segmented_long_profiles_match_the_workgroup_kernel(tango, N, nb):
+    """Profiles of 8192 points and more are stepped in 512-point segments (three kernels, a work space); the result
+    must be the one-workgroup-per-profile kernel's: profiles, EWMA memories, residual history, stop iterations."""
+    from tango_amd.ensemble import OneFieldEnsemble, shestakov_ensemble
+    ens = shestakov_ensemble(nb, N)
+    for fixed, tol, total in ((True, 1e-11, 10), (False, 2e-3, 30)):
+        A = OneFieldEnsemble(ens, a_prof=0.3, tol=tol, max_iter=total, fixed_count=fixed, segmented=False)
+        B = OneFieldEnsemble(ens, a_prof=0.3, tol=tol, max_iter=total, fixed_count=fixed)
+        assert A.work is None and B.work is not None
+        for _ in range(total):
+            A.step()
+            B.step()
+        ia, ib = A.iters.to_host(), B.iters.to_host()
+        assert np.array_equal(ia, ib) and np.array_equal(A.status.to_host(), B.status.to_host())
+        if not fixed:
+            assert np.all(ia < total) and np.all(A.status.to_host() & 1)
+        bar = 2e-9          # cond ~1e11 and beyond: two elimination orders agree to about cond x eps
+        for x, y in ((A.u, B.u), (A.uE, B.uE), (A.DE, B.DE), (A.cE, B.cE)):
+            assert relerr(y.to_host(), x.to_host()) < bar
+        k = int(ia.min())
+        assert np.allclose(A.err.to_host()[:, :k], B.err.to_host()[:, :k], rtol=1e-5, atol=1e-11)
