@@ -65,6 +65,13 @@ SegWork seg_carve(void *work, int64_t nb, int64_t n) {
     return W;
 }
 
+// Position of lane r of a profile (r = 0 .. n/8-1) in the per-lane work arrays: transposed so that the reduce kernel,
+// whose thread t owns lanes 8t .. 8t+7, reads and writes them coalesced (lane 8t+i at i n/64 + t).
+__device__ __forceinline__ int64_t lane_slot(int64_t profile, int n, int r) {
+    const int T = n / 64;
+    return profile * (n / 8) + (int64_t)(r & 7) * T + (r >> 3);
+}
+
 // ------------------------------------------------------------------------------------------
 // Phase 0 replaces uE, DE and cE in place while neighbouring segments still need the old values next to their
 // boundaries: those are copied aside first (one thread per boundary).
@@ -113,7 +120,8 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
     const int j0 = s * kSeg + t * P;                 // first point of this lane within the profile
     const int64_t off = b * S_.n;
     const int64_t woff = off + (int64_t)s * kSeg;
-    const int64_t lane_id = (b * S_.n + (int64_t)s * kSeg) / P + t;   // index of this lane among all lanes
+    const int lane_r = s * 64 + t;                                    // this lane within its profile
+    const int64_t lane_id = lane_slot(b, n, lane_r);                  // its slot in the per-lane work arrays
     const bool first_lane = (s == 0 && t == 0);      // holds the first point of the profile
     const bool last_lane = (s == S - 1 && t == 63);  // holds the last point of the profile (Dirichlet row)
     const Recip rc(Q.dx, Q.dt_b ? Q.dt_b[b] : Q.dt);
@@ -314,7 +322,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
     } else {
         // back substitution with this lane's last unknown y and its left neighbour's (any segment)
         const double y = W.y[lane_id];
-        const double yl = first_lane ? 0.0 : W.y[lane_id - 1];
+        const double yl = first_lane ? 0.0 : W.y[lane_slot(b, n, lane_r - 1)];
         double x[P];
         x[P - 1] = y;
 #pragma unroll
@@ -359,18 +367,18 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
         return;
     }
     const int t = g.t();
-    const int64_t base = b * rows;
     ChunkElim<P, false> el;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int r = t * P + i;
-        const int64_t k = base + r;
+        const int64_t k = lane_slot(b, n, r);
         const double e = W.row[0][k], l = W.row[1][k], f = W.row[2][k], rho = W.row[3][k];
         // first-row form of the lane to the right; an identity row past the end of the profile
         const bool more = r + 1 < rows;
-        const double F0 = more ? W.row[4][k + 1] : 0.0;
-        const double E0 = more ? W.row[5][k + 1] : 0.0;
-        const double T0 = more ? W.row[6][k + 1] : 1.0;
+        const int64_t k1 = lane_slot(b, n, more ? r + 1 : r);
+        const double F0 = more ? W.row[4][k1] : 0.0;
+        const double E0 = more ? W.row[5][k1] : 0.0;
+        const double T0 = more ? W.row[6][k1] : 1.0;
         // l y_{r-1} + (1 - e L0) y_r - e E0 y_{r+1} = f - e F0 with slack rho - e T0, the diagonal formed from the
         // slack (all terms of one sign for an M-matrix), as in ChunkElim::finish
         const double sig = rho - e * T0;
@@ -382,7 +390,7 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
     double y[P];
     el.finish(g, y);
 #pragma unroll
-    for (int i = 0; i < P; ++i) W.y[base + t * P + i] = y[i];
+    for (int i = 0; i < P; ++i) W.y[lane_slot(b, n, t * P + i)] = y[i];
     const int sing = g.any(el.singular);
 
     // residual norm of the profile from the segments' partial sums (tango/fieldgroups.py:140, tango/solver.py:464-470)
