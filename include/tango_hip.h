@@ -111,6 +111,17 @@ int tg_ddx(const double *u, double dx, int edge_order, double *out, int64_t nb, 
 /* window must be odd (callers add one to even windows as the reference's Smoother does) */
 int tg_moving_average(const double *x, int window, double *out, int64_t nb, int64_t n,
                       tg_stream stream);
+/* ---- resampling between the transport grid and a turbulence grid ----------------------------------
+ * tango/interfacegrids_gene.py:51-57 (map_profile_onto_turb_grid) and :446-484 (extend_with_zeros_both_sides) call
+ * scipy.interpolate.InterpolatedUnivariateSpline: the cubic spline through all points with not-a-knot ends.  The
+ * same curve is built here for every row of yin (nb, nin) over the increasing grid xin (nin,) and evaluated at
+ * xout[out_lo:out_hi]; the other entries of yout (nb, nout) are set to zero (a coefficient extended with zeros onto
+ * a larger grid); nonneg != 0 replaces negative values by zero (enforcePositive).  Points of xout outside xin
+ * continue the end cubics, as the reference's spline does. */
+size_t tg_spline_work_bytes(int64_t nb, int64_t nin);
+int tg_spline_resample(const double *xin, const double *yin, int64_t nb, int64_t nin, const double *xout, int64_t nout,
+                       int64_t out_lo, int64_t out_hi, int nonneg, double *yout, void *work, size_t work_bytes,
+                       tg_stream stream);
 /* Gamma = -(dn/dx)^3 / n^2 */
 int tg_shestakov_flux(const double *nprof, double dx, double *flux, int64_t nb, int64_t n,
                       tg_stream stream);

@@ -746,6 +746,42 @@ def run_3f(n0, pi0, pe0, dt, dx, BCs, nu0, x, a_turb, a_prof, tol, max_iter,
 
 
 # --------------------------------------------------------------------------------------
+# grid mapping (tango/interfacegrids_gene.py:35-87, :446-484)
+# --------------------------------------------------------------------------------------
+def spline_resample(xin, yin, xout):
+    """Cubic interpolating spline with not-a-knot ends through (xin, yin) at xout, in the second-derivative form:
+    the curve scipy.interpolate.InterpolatedUnivariateSpline (FITPACK, k = 3; SciPy is unpinned by the reference,
+    1.15.3 here) returns for the same points.  1-D arrays; dense solve."""
+    x, y = np.asarray(xin, dtype=float), np.asarray(yin, dtype=float)
+    n = len(x)
+    h = np.diff(x)
+    T = np.zeros((n, n)); r = np.zeros(n)
+    for i in range(1, n - 1):
+        T[i, i - 1], T[i, i], T[i, i + 1] = h[i - 1], 2 * (h[i - 1] + h[i]), h[i]
+        r[i] = 6 * ((y[i + 1] - y[i]) / h[i] - (y[i] - y[i - 1]) / h[i - 1])
+    T[0, 0], T[0, 1], T[0, 2] = h[1], -(h[0] + h[1]), h[0]
+    T[-1, -1], T[-1, -2], T[-1, -3] = h[-2], -(h[-1] + h[-2]), h[-1]
+    M = np.linalg.solve(T, r)
+    xo = np.asarray(xout, dtype=float)
+    i = np.clip(np.searchsorted(x, xo, side='right') - 1, 0, n - 2)
+    hi = h[i]; dl = xo - x[i]; dr = x[i + 1] - xo
+    return ((M[i] * dr ** 3 + M[i + 1] * dl ** 3) / (6 * hi) + (y[i] / hi - M[i] * hi / 6) * dr
+            + (y[i + 1] / hi - M[i + 1] * hi / 6) * dl)
+
+
+def extend_with_zeros_both_sides(xSmall, fSmall, xLarge, enforce_positive=False):
+    """tango/interfacegrids_gene.py:446-484."""
+    xS, xL = np.asarray(xSmall, dtype=float), np.asarray(xLarge, dtype=float)
+    out = np.zeros_like(xL)
+    lo = np.where(xL > xS[0])[0][0]
+    hi = np.where(xL < xS[-1])[0][-1]
+    out[lo:hi + 1] = spline_resample(xS, fSmall, xL[lo:hi + 1])
+    if enforce_positive:
+        out[out < 0] = 0
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # synthetic ensembles of the benchmark configurations
 # --------------------------------------------------------------------------------------
 def shestakov_ensemble(nb, n, seed=12345):

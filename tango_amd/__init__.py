@@ -15,5 +15,6 @@ from . import solver  # noqa: F401
 from . import extras  # noqa: F401
 from . import ensemble  # noqa: F401
 from . import restart  # noqa: F401
+from . import interfacegrids_gene  # noqa: F401
 
 __version__ = '0.1.0'

@@ -235,6 +235,27 @@ def moving_average(x, window):
     return cx.out(out)
 
 
+def spline_resample(xin, yin, xout, lo=0, hi=None, nonneg=False):
+    """Not-a-knot cubic spline through (xin, yin rows) evaluated at xout[lo:hi], zeros elsewhere (the curve of
+    scipy.interpolate.InterpolatedUnivariateSpline as used by tango/interfacegrids_gene.py:51-57, :446-484)."""
+    xin = np.ascontiguousarray(xin, dtype=np.float64)
+    xout = np.ascontiguousarray(xout, dtype=np.float64)
+    assert xin.ndim == 1 and xout.ndim == 1 and xin.size >= 4, 'grids must be 1-D with at least 4 points'
+    assert np.all(np.diff(xin) > 0), 'the input grid must be strictly increasing'
+    hi = xout.size if hi is None else hi
+    cx = _Ctx()
+    dy = cx.arr(yin, 'values')
+    assert cx.n == xin.size, 'values and grid must have the same length'
+    nb = dy.shape[0]
+    dxin, dxout = DeviceArray.from_host(xin), DeviceArray.from_host(xout)
+    out = cx.new((nb, xout.size))
+    wb = int(lib.tg_spline_work_bytes(nb, xin.size))
+    work = DeviceArray((wb // 8,))
+    check(lib.tg_spline_resample(dxin.ptr, ptr_of(dy), nb, xin.size, dxout.ptr, xout.size, int(lo), int(hi), int(bool(nonneg)),
+                                 out.ptr, work.ptr, wb, H.stream()))
+    return cx.out(out)
+
+
 def shestakov_flux(n_prof, dx):
     """tango/extras/shestakov_nonlinear_diffusion.py:51-61."""
     cx = _Ctx()

@@ -277,6 +277,87 @@ stream_probe_kernel(const double2 *__restrict__ a, const double2 *__restrict__ b
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Cubic interpolating spline with not-a-knot ends, the curve scipy.interpolate.InterpolatedUnivariateSpline
+// (FITPACK, k = 3) passes through the same points, in the second-derivative ("moment") form: the interior moments
+// M_1..M_{n-2} solve a tridiagonal system (the end moments follow from the continuity of the third derivative at
+// x_1 and x_{n-2} and are eliminated from rows 1 and n-2).  Used to move profiles and transport coefficients
+// between the transport grid and a turbulence grid (tango/interfacegrids_gene.py:51-57, :446-484).
+// ------------------------------------------------------------------------------------------
+__global__ void spline_rows_kernel(const double *__restrict__ x, const double *__restrict__ y, int64_t nb, int n,
+                                   double *__restrict__ A, double *__restrict__ B, double *__restrict__ C,
+                                   double *__restrict__ D) {
+    const int m = n - 2;
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < nb * m; k += stride) {
+        const int64_t b = k / m;
+        const int i = (int)(k - b * m) + 1;          // interior point 1 .. n-2
+        const double hm = x[i] - x[i - 1], hp = x[i + 1] - x[i];
+        const double *yr = y + b * n;
+        const double rhs = 6.0 * ((yr[i + 1] - yr[i]) / hp - (yr[i] - yr[i - 1]) / hm);
+        double c = hm, d = 2.0 * (hm + hp), a = hp;
+        if (i == 1) {              // M_0 = ((h_0 + h_1) M_1 - h_0 M_2) / h_1
+            d += hm * (hm + hp) / hp;
+            a -= hm * hm / hp;
+            c = 0.0;
+        }
+        if (i == n - 2) {          // M_{n-1} = ((h_{n-2} + h_{n-3}) M_{n-2} - h_{n-2} M_{n-3}) / h_{n-3}
+            d += hp * (hp + hm) / hm;
+            c -= hp * hp / hm;
+            a = 0.0;
+        }
+        A[k] = a;
+        B[k] = d;
+        C[k] = c;
+        D[k] = rhs;
+    }
+}
+
+__global__ void spline_eval_kernel(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ Mi,
+                                   int64_t nb, int n, const double *__restrict__ xo, int no, int lo, int hi, int nonneg,
+                                   double *__restrict__ out) {
+    const int m = n - 2;
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < nb * no; k += stride) {
+        const int64_t b = k / no;
+        const int j = (int)(k - b * no);
+        double v = 0.0;
+        if (j >= lo && j < hi) {
+            const double xv = xo[j];
+            // interval i with x_i <= xv < x_{i+1}, end intervals beyond the ends (the end cubics continue)
+            int a = 0, z = n - 1;
+            while (z - a > 1) {
+                const int mid = (a + z) >> 1;
+                if (x[mid] <= xv) a = mid;
+                else z = mid;
+            }
+            const int i = a;
+            const double *Mr = Mi + b * m;
+            const double *yr = y + b * n;
+            auto moment = [&](int q) -> double {
+                if (q == 0) {
+                    const double h0 = x[1] - x[0], h1 = x[2] - x[1];
+                    return ((h0 + h1) * Mr[0] - h0 * Mr[1]) / h1;
+                }
+                if (q == n - 1) {
+                    const double hz = x[n - 1] - x[n - 2], hy = x[n - 2] - x[n - 3];
+                    return ((hz + hy) * Mr[m - 1] - hz * Mr[m - 2]) / hy;
+                }
+                return Mr[q - 1];
+            };
+            const double h = x[i + 1] - x[i];
+            const double M0 = moment(i), M1 = moment(i + 1);
+            const double dl = xv - x[i], dr = x[i + 1] - xv;
+            v = (M0 * dr * dr * dr + M1 * dl * dl * dl) / (6.0 * h) + (yr[i] / h - M0 * h / 6.0) * dr + (yr[i + 1] / h - M1 * h / 6.0) * dl;
+            if (nonneg && v < 0.0) v = 0.0;
+        }
+        out[k] = v;
+    }
+}
+
 __global__ void status_reduce_kernel(const int32_t *__restrict__ status, int64_t nb, unsigned long long *counts) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -908,6 +989,30 @@ int tg_moving_average(const double *x, int window, double *out, int64_t nb, int6
     if (window > n) return fail(TG_ERR_ARG, "window larger than the grid%s");
     if (nb == 0) return TG_OK;
     hipLaunchKernelGGL(moving_average_kernel, dim3(grid_1d(nb * n, 256)), dim3(256), 0, S(stream), x, window, out, nb, (int)n);
+    return launch_check();
+}
+
+size_t tg_spline_work_bytes(int64_t nb, int64_t nin) {
+    if (nb <= 0 || nin < 4) return 0;
+    return ((size_t)5 * (size_t)nb * (size_t)(nin - 2) * sizeof(double) + 255) & ~(size_t)255;
+}
+
+int tg_spline_resample(const double *xin, const double *yin, int64_t nb, int64_t nin, const double *xout, int64_t nout,
+                       int64_t out_lo, int64_t out_hi, int nonneg, double *yout, void *work, size_t work_bytes, tg_stream stream) {
+    if (nb < 0 || nin < 4 || nin - 2 > 16384 || nout < 1 || nout > INT32_MAX) return fail(TG_ERR_ARG, "spline: need 4 <= nin <= 16386 and nout >= 1%s");
+    if (!xin || !yin || !xout || !yout) return fail(TG_ERR_ARG, "NULL array%s");
+    if (out_lo < 0 || out_hi > nout || out_lo > out_hi) return fail(TG_ERR_ARG, "spline: bad output range%s");
+    if (!work || work_bytes < tg_spline_work_bytes(nb, nin)) return fail(TG_ERR_ARG, "spline: work space too small (tg_spline_work_bytes)%s");
+    if (nb == 0) return TG_OK;
+    const int64_t m = nin - 2, plane = nb * m;
+    double *A = static_cast<double *>(work), *B = A + plane, *C = B + plane, *D = C + plane, *M = D + plane;
+    hipLaunchKernelGGL(spline_rows_kernel, dim3(grid_1d(plane, 256)), dim3(256), 0, S(stream), xin, yin, nb, (int)nin, A, B, C, D);
+    if (int e = launch_check()) return e;
+    if (int e = dispatch_group<TridiagLauncher>(nb, (int)m, S(stream), (const double *)A, (const double *)B, (const double *)C,
+                                                (const double *)D, M, (int32_t *)nullptr))
+        return e;
+    hipLaunchKernelGGL(spline_eval_kernel, dim3(grid_1d(nb * nout, 256)), dim3(256), 0, S(stream), xin, yin, (const double *)M, nb,
+                       (int)nin, xout, (int)nout, (int)out_lo, (int)out_hi, nonneg, yout);
     return launch_check();
 }
 

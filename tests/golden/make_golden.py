@@ -389,6 +389,41 @@ def g15():
     save('g15_decorators', **out)
 
 
+def g16():
+    """Grid mapping with the transport grid outside the turbulence grid (tango/interfacegrids_gene.py:35-87): the
+    class's three maps on sample data, and a one-field run whose flux model lives on a finer, shorter grid."""
+    from tango import interfacegrids_gene as ig
+    xT = np.linspace(0.0, 1.0, 60)
+    xG = np.linspace(0.13, 0.81, 150)
+    gm = ig.GridInterfaceTangoOutside(xT, xG)
+    prof = 1.2 - 0.7 * xT ** 2 + 0.05 * np.sin(9 * xT)
+    Dg = 0.3 * np.exp(-((xG - 0.45) / 0.2) ** 2) - 0.004
+    cg = 0.1 * np.sin(7 * xG) * (xG - 0.13) * (0.81 - xG)
+    out = dict(xT=xT, xG=xG, prof=prof, Dg=Dg, cg=cg, prof_on_G=gm.map_profile_onto_turb_grid(prof))
+    out['D_on_T'], out['c_on_T'] = gm.map_transport_coeffs_onto_transport_grid(Dg, cg)
+    xn = np.sort(np.concatenate(([0.0, 1.0], np.random.default_rng(3).uniform(0, 1, 38))))      # non-uniform grid
+    yn = np.cos(3 * xn) + xn
+    xq = np.linspace(-0.05, 1.05, 97)
+    import scipy.interpolate
+    out.update(xn=xn, yn=yn, xq=xq, yq=scipy.interpolate.InterpolatedUnivariateSpline(xn, yn)(xq))
+    # a run: transport grid 0..1 (N=120), turbulence grid 0.1..0.9 (N=300); Shestakov flux on the turbulence grid
+    N, NG = 120, 300
+    x = np.linspace(0, 1, N); dx = x[1] - x[0]
+    xg = np.linspace(0.1, 0.9, NG); dxg = xg[1] - xg[0]
+    th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
+    lm = lodestro_method.lm(0.3, 1.0, th)
+    f0 = multifield.Field(label='n', rightBC=0.05, profile_mminus1=1 - 0.5 * x, compute_all_H=ComputeAllH1F(1.0, 0.3),
+                          gridMapper=ig.GridInterfaceTangoOutside(x, xg), lodestroMethod=lm)
+    multifield.check_fields_initialize([f0])
+    call = multifield.ComputeAllHAllFields([f0], lodestro_method.TurbulenceHandler(dxg, x, shest.AnalyticFluxModel(dxg)))
+    s = tsolver.Solver(1, x, np.array([0, 0.5]), 25, 1e-14, call, [f0])
+    s.take_timestep()
+    out.update(run_N=N, run_NG=NG, run_err=s.errHistoryFinal.copy(), run_final=s.profiles['n'].copy(),
+               run_it2=s.profilesAllIterations['n'][2].copy(), run_DE=lm._EWMATurbD._yEWMA_lminus1.copy())
+    print('run iterations', len(s.errHistoryFinal), 'last err', s.errHistoryFinal[-1])
+    save('g16_gridmap', **out)
+
+
 # ---------------------------------------------------------------- G9 three-field trajectories
 def run_ref_3f(N, nu0, BCs, a_turb, a_prof, tol, maxit, inner=0, dt=1e6, keep=()):
     dx = 1 / (N - 1); x = np.arange(N) * dx
@@ -480,6 +515,6 @@ def g11():
 
 
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15']
+    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16']
     for w in which:
         globals()[w]()

@@ -253,3 +253,13 @@ def test_g13_timesteps(golden):
     for m, (u, it, err) in enumerate(out):
         assert relerr(u, g['profiles'][m]) < 1e-13
         assert np.allclose(err, g['errs'][m, :it], rtol=1e-9, atol=1e-15)
+
+
+def test_g16_grid_mapping(golden):
+    """Spline resampling and zero extension (tango/interfacegrids_gene.py:35-87, :446-484)."""
+    g = golden('g16_gridmap')
+    assert relerr(orc.spline_resample(g['xT'], g['prof'], g['xG']), g['prof_on_G']) < 1e-13
+    assert relerr(orc.spline_resample(g['xn'], g['yn'], g['xq']), g['yq']) < 1e-12
+    assert relerr(orc.extend_with_zeros_both_sides(g['xG'], g['Dg'], g['xT'], True), g['D_on_T']) < 1e-13
+    assert relerr(orc.extend_with_zeros_both_sides(g['xG'], g['cg'], g['xT']), g['c_on_T']) < 1e-13
+    assert np.all(g['D_on_T'] >= 0) and g['D_on_T'][0] == 0 and g['D_on_T'][-1] == 0
