@@ -406,6 +406,9 @@ def g16():
     xq = np.linspace(-0.05, 1.05, 97)
     import scipy.interpolate
     out.update(xn=xn, yn=yn, xq=xq, yq=scipy.interpolate.InterpolatedUnivariateSpline(xn, yn)(xq))
+    ge = ig.TangoOutsideExtrapCoeffs(xT, xG, 0.55, 0.7, 2)
+    out['ext_prof_on_G'] = ge.map_profile_onto_turb_grid(prof)
+    out['ext_D_on_T'], out['ext_c_on_T'] = ge.map_transport_coeffs_onto_transport_grid(Dg, cg)
     # a run: transport grid 0..1 (N=120), turbulence grid 0.1..0.9 (N=300); Shestakov flux on the turbulence grid
     N, NG = 120, 300
     x = np.linspace(0, 1, N); dx = x[1] - x[0]

@@ -213,6 +213,13 @@ def test_grid_mapping_golden(tango, golden):
     assert relerr(out[1], 2 * g['prof_on_G'] + 1) < 1e-12
     with pytest.raises(AssertionError):
         ig.GridInterfaceTangoOutside(g['xG'], g['xT'])
+    # coefficients extrapolated by a fitted polynomial beyond the trusted part of the turbulence grid (:90-178, :248-298)
+    ge = ig.TangoOutsideExtrapCoeffs(g['xT'], g['xG'], 0.55, 0.7, 2)
+    assert relerr(ge.map_profile_onto_turb_grid(g['prof']), g['ext_prof_on_G']) < 1e-12
+    D, c = ge.map_transport_coeffs_onto_transport_grid(g['Dg'], g['cg'])
+    assert relerr(D, g['ext_D_on_T']) < 1e-11 and relerr(c, g['ext_c_on_T']) < 1e-11
+    D2, c2 = ge.map_transport_coeffs_onto_transport_grid(np.stack([g['Dg'], 2 * g['Dg']]), np.stack([g['cg'], -g['cg']]))
+    assert relerr(D2[0], g['ext_D_on_T']) < 1e-11 and relerr(c2[1], -g['ext_c_on_T']) < 1e-11
 
 
 def test_solver_with_grid_mapper(tango, golden):
