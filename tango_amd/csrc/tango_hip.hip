@@ -454,6 +454,10 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         wt.fetch(S_.DE + woff, r2);
         wt.fetch(S_.cE + woff, r3);
         wt.fetch(S_.um1 + woff, r4);
+        double2 r5[GENERAL ? 4 : 1];
+        if constexpr (GENERAL) {
+            if (external) wt.fetch(Q.flux + woff, r5);
+        }
         if constexpr (NT >= 4) {
             wt.stage(0, r0);
             wt.stage(1, r1);
@@ -483,6 +487,14 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         Tile::sync();
         wt.take(0, um1);
         Tile::sync();
+        if constexpr (GENERAL) {
+            if (external) {
+                wt.stage(0, r5);
+                Tile::sync();
+                wt.take(0, fl);
+                Tile::sync();
+            }
+        }
     };
     auto load_state_lane = [&]() {
         load_chunk<P, FULL>(S_.u + off, n, j0, u + 1, 0.0);
@@ -490,6 +502,15 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         load_chunk<P, FULL>(S_.DE + off, n, j0, DE, 0.0);
         load_chunk<P, FULL>(S_.cE + off, n, j0, cE, 0.0);
         load_chunk<P, FULL>(S_.um1 + off, n, j0, um1, 0.0);
+        if constexpr (GENERAL) {
+            if (external) load_chunk<P, FULL>(Q.flux + off, n, j0, fl, 0.0);
+        }
+    };
+    // P points per lane of one or two arrays that all profiles share (n doubles each; a1 may be null).  Plain
+    // per-lane loads: these arrays stay in the caches, and a detour through the LDS tiles measured slower.
+    auto load_shared = [&](const double *a0, double *d0, const double *a1, double *d1) {
+        load_chunk<P, FULL>(a0, n, j0, d0, 1.0);
+        if (a1) load_chunk<P, FULL>(a1, n, j0, d1, 1.0);
     };
     if constexpr (COOP_ALWAYS) {
         load_state_coop();
@@ -499,9 +520,64 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     } else {
         load_state_lane();
     }
-    if constexpr (GENERAL) {
-        if (external) load_chunk<P, FULL>(Q.flux + off, n, j0, fl, 0.0);
-    }
+
+    // The new profile, and the three memories when the turbulence step ran, go back the way they came.
+    auto store_coop = [&](auto pred, bool prof, bool mem) {
+        const uint64_t amask = decltype(pred)::value ? __ballot(active) : ~0ull;   // lanes whose profile was stepped
+        constexpr bool PR = decltype(pred)::value;
+        if constexpr (NT >= 4) {
+            if (prof) wt.put(0, u + 1);
+            if (mem) {
+                wt.put(1, ue);
+                wt.put(2, DE);
+                wt.put(3, cE);
+            }
+            Tile::sync();
+            if (prof) wt.template flush<PR>(0, S_.u + woff, amask);
+            if (mem) {
+                if (!external) wt.template flush<PR>(1, S_.uE + woff, amask);
+                wt.template flush<PR>(2, S_.DE + woff, amask);
+                wt.template flush<PR>(3, S_.cE + woff, amask);
+            }
+            Tile::sync();
+        } else {
+            if (mem) {
+                wt.put(0, DE);
+                wt.put(1, cE);
+                Tile::sync();
+                wt.template flush<PR>(0, S_.DE + woff, amask);
+                wt.template flush<PR>(1, S_.cE + woff, amask);
+                Tile::sync();
+            }
+            if (prof) wt.put(0, u + 1);
+            if (mem) wt.put(1, ue);
+            Tile::sync();
+            if (prof) wt.template flush<PR>(0, S_.u + woff, amask);
+            if (mem && !external) wt.template flush<PR>(1, S_.uE + woff, amask);
+            Tile::sync();
+        }
+    };
+    auto store_lane = [&](bool prof, bool mem) {
+        if (prof) store_chunk<P, FULL>(S_.u + off, n, j0, u + 1);
+        if (mem) {
+            if (!external) store_chunk<P, FULL>(S_.uE + off, n, j0, ue);
+            store_chunk<P, FULL>(S_.DE + off, n, j0, DE);
+            store_chunk<P, FULL>(S_.cE + off, n, j0, cE);
+        }
+    };
+    auto store_state = [&](bool prof, bool mem) {
+        if constexpr (COOP_ALWAYS) {
+            store_coop(std::false_type{}, prof, mem);
+        } else if constexpr (COOP_T) {
+            if (coop) store_coop(std::true_type{}, prof, mem);
+            else store_lane(prof, mem);
+        } else {
+            store_lane(prof, mem);
+        }
+    };
+    // a single-iteration launch of the general form stores the memories as soon as they are final, which frees
+    // their registers for the assembly and the solve
+    constexpr bool EARLY = GENERAL && !MULTI;
 
     // this profile needs no further iteration (uniform over its lane group)
     constexpr bool PACKED = COOP_T && !COOP_ALWAYS;    // wavefronts that may carry profiles that were never active
@@ -542,7 +618,14 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                     for (int i = 0; i < P; ++i) ue[i] = Q.a_prof * u[i + 1] + omp * u[i + 1];
                 }
             }
-            double Dn[G::kBlock ? 1 : P], cn[G::kBlock ? 1 : P];
+            constexpr bool INPLACE = G::kBlock || GENERAL;    // short of registers: update the memories point by point
+            double Dn[INPLACE ? 1 : P], cn[INPLACE ? 1 : P];
+            // <g^xx> and <|grad x|> on the turbulence grid (tango/lodestro_method.py:352-353), one chunk per lane
+            double gxt[GENERAL ? P : 1], grt[GENERAL ? P : 1];
+            if constexpr (GENERAL) {
+                if (Q.gxx_turb) load_shared(Q.gxx_turb, gxt, Q.gradx_turb, grt);
+                else if (Q.gradx_turb) load_shared(Q.gradx_turb, grt, nullptr, nullptr);
+            }
             const double wl = g.from_left(ue[P - 1], 1, 0.0);
             const double wr = g.from_right(ue[0], 1, 0.0);
 #pragma unroll
@@ -562,24 +645,26 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                     double gx = 1.0, gr = 1.0;
                     if constexpr (GENERAL) {
                         flux = external ? fl[i] : flux;
-                        gx = Q.gxx_turb ? Q.gxx_turb[jc] : 1.0;
-                        gr = Q.gradx_turb ? Q.gradx_turb[jc] : 1.0;
+                        gx = Q.gxx_turb ? gxt[i] : 1.0;
+                        gr = Q.gradx_turb ? grt[i] : 1.0;
                     }
                     double DH, cH, thv;
                     flux_split_point(flux, p, dpdx, gx, gr, th, D, c, DH, cH, thv);
                 } else {
                     shestakov_split_point(p, dpdx, th, D, c);   // built-in flux, Cartesian: one quotient
                 }
-                if constexpr (G::kBlock) {     // large grids are short of registers: update in place
-                    DE[i] = Q.a_turb * D + omt * (seeded ? DE[i] : D);
-                    cE[i] = Q.a_turb * c + omt * (seeded ? cE[i] : c);
+                if constexpr (INPLACE) {
+                    const double nD = Q.a_turb * D + omt * (seeded ? DE[i] : D);
+                    const double nc = Q.a_turb * c + omt * (seeded ? cE[i] : c);
+                    DE[i] = hold ? DE[i] : nD;
+                    cE[i] = hold ? cE[i] : nc;
                 } else {
                     Dn[i] = D;
                     cn[i] = c;
                 }
             }
             // EWMA of D and c (tango/lodestro_method.py:368-369)
-            if constexpr (G::kBlock) {
+            if constexpr (INPLACE) {
             } else if constexpr (kShared) {
 #pragma unroll
                 for (int i = 0; i < P; ++i) {
@@ -603,26 +688,46 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             }
         }
 
-        // H2 = V' D <g^xx>, H3 = -V' c <|grad x|> (tango/lodestro_method.py:400-405) at local point k (0..P-1)
-        auto H2at = [&](int k) -> double {
-            if constexpr (GENERAL) {
-                if (geom) {
-                    const int j = j0 + k;
-                    const int jc = (FULL || j < n) ? j : n - 1;
-                    return Q.Vprime[jc] * DE[k] * (Q.gxx ? Q.gxx[jc] : 1.0);
+        // H2 = V' D <g^xx>, H3 = -V' c <|grad x|> (tango/lodestro_method.py:400-405); without geometry arrays they
+        // are the EWMA memories themselves
+        double H2v[GENERAL ? P : 1], H3v[GENERAL ? P : 1];
+        if constexpr (GENERAL) {
+            if (geom) {
+                double vp[P], gq[P];
+                load_shared(Q.Vprime, vp, Q.gxx, gq);
+                if (Q.gxx) {
+#pragma unroll
+                    for (int i = 0; i < P; ++i) H2v[i] = vp[i] * DE[i] * gq[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < P; ++i) H2v[i] = vp[i] * DE[i] * 1.0;
+                }
+                if (Q.gradx) {
+                    load_shared(Q.gradx, gq, nullptr, nullptr);
+#pragma unroll
+                    for (int i = 0; i < P; ++i) H3v[i] = -vp[i] * cE[i] * gq[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < P; ++i) H3v[i] = -vp[i] * cE[i] * 1.0;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    H2v[i] = DE[i];
+                    H3v[i] = -cE[i];
                 }
             }
-            return DE[k];
+        }
+        if constexpr (EARLY) {
+            if (!Q.frozen_turb) store_state(false, true);
+        }
+        auto H2at = [&](int k) -> double {
+            if constexpr (GENERAL) return H2v[k];
+            else return DE[k];
         };
         auto H3at = [&](int k) -> double {
-            if constexpr (GENERAL) {
-                if (geom) {
-                    const int j = j0 + k;
-                    const int jc = (FULL || j < n) ? j : n - 1;
-                    return -Q.Vprime[jc] * cE[k] * (Q.gradx ? Q.gradx[jc] : 1.0);
-                }
-            }
-            return -cE[k];
+            if constexpr (GENERAL) return H3v[k];
+            else return -cE[k];
         };
         const double h2first = H2at(0), h3first = H3at(0), h2last = H2at(P - 1), h3last = H3at(P - 1);
         const double h2l = g.from_left(h2last, 1, 0.0), h3l = g.from_left(h3last, 1, 0.0);
@@ -737,55 +842,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         if (G::kBlock ? done : !__any(!done)) break;
     }
 
-    auto store_state_coop = [&](auto pred) {
-        const bool turb = !Q.frozen_turb;
-        const uint64_t amask = decltype(pred)::value ? __ballot(active) : ~0ull;   // lanes whose profile was stepped
-        if constexpr (NT >= 4) {
-            wt.put(0, u + 1);
-            if (turb) {
-                wt.put(1, ue);
-                wt.put(2, DE);
-                wt.put(3, cE);
-            }
-            Tile::sync();
-            wt.template flush<decltype(pred)::value>(0, S_.u + woff, amask);
-            if (turb) {
-                if (!external) wt.template flush<decltype(pred)::value>(1, S_.uE + woff, amask);
-                wt.template flush<decltype(pred)::value>(2, S_.DE + woff, amask);
-                wt.template flush<decltype(pred)::value>(3, S_.cE + woff, amask);
-            }
-        } else {
-            wt.put(0, u + 1);
-            if (turb) wt.put(1, ue);
-            Tile::sync();
-            wt.template flush<decltype(pred)::value>(0, S_.u + woff, amask);
-            if (turb) {
-                if (!external) wt.template flush<decltype(pred)::value>(1, S_.uE + woff, amask);
-                Tile::sync();
-                wt.put(0, DE);
-                wt.put(1, cE);
-                Tile::sync();
-                wt.template flush<decltype(pred)::value>(0, S_.DE + woff, amask);
-                wt.template flush<decltype(pred)::value>(1, S_.cE + woff, amask);
-            }
-        }
-    };
-    auto store_state_lane = [&]() {
-        store_chunk<P, FULL>(S_.u + off, n, j0, u + 1);
-        if (!Q.frozen_turb) {
-            if (!external) store_chunk<P, FULL>(S_.uE + off, n, j0, ue);
-            store_chunk<P, FULL>(S_.DE + off, n, j0, DE);
-            store_chunk<P, FULL>(S_.cE + off, n, j0, cE);
-        }
-    };
-    if constexpr (COOP_ALWAYS) {
-        store_state_coop(std::false_type{});
-    } else if constexpr (COOP_T) {
-        if (coop) store_state_coop(std::true_type{});
-        else store_state_lane();
-    } else {
-        store_state_lane();
-    }
+    store_state(true, !EARLY && !Q.frozen_turb);
     if (t == 0 && active) {
         S_.iters[b] = it0;
         S_.status[b] = st;
@@ -846,15 +903,21 @@ struct Picard1fLauncher {
         geometry<G>(nb, grid, block, lds);
         uintptr_t al = reinterpret_cast<uintptr_t>(st->u) | reinterpret_cast<uintptr_t>(st->um1) |
                        reinterpret_cast<uintptr_t>(st->uE) | reinterpret_cast<uintptr_t>(st->DE) |
-                       reinterpret_cast<uintptr_t>(st->cE) | reinterpret_cast<uintptr_t>(q->flux);
+                       reinterpret_cast<uintptr_t>(st->cE) | reinterpret_cast<uintptr_t>(q->flux) |
+                       reinterpret_cast<uintptr_t>(q->Vprime) | reinterpret_cast<uintptr_t>(q->gxx) |
+                       reinterpret_cast<uintptr_t>(q->gradx) | reinterpret_cast<uintptr_t>(q->gxx_turb) |
+                       reinterpret_cast<uintptr_t>(q->gradx_turb);
         const bool full = (n == P * G::T) && (al & 15) == 0;
         const bool general = q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly;
         const bool multi = q->iters_per_launch > 1;
         if (kWaveCoop<P, G, true> && full) lds += (size_t)(block / 64) * kCoopTiles<G> * WaveTile<8>::kDoubles * sizeof(double);
 #define TG_LAUNCH_1F(F, GEN, M) hipLaunchKernelGGL((picard_1f_kernel<P, G, F, GEN, M>), dim3(grid), dim3(block), lds, s, *st, *q)
-        if (general) {
+        if (general && multi) {
             if (full) TG_LAUNCH_1F(true, true, true);
             else TG_LAUNCH_1F(false, true, true);
+        } else if (general) {
+            if (full) TG_LAUNCH_1F(true, true, false);
+            else TG_LAUNCH_1F(false, true, false);
         } else if (multi) {
             if (full) TG_LAUNCH_1F(true, false, true);
             else TG_LAUNCH_1F(false, false, true);
