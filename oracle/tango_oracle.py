@@ -781,6 +781,64 @@ def extend_with_zeros_both_sides(xSmall, fSmall, xLarge, enforce_positive=False)
     return out
 
 
+def extend_with_zeros_left_side(xIn, fIn, xOut, enforce_positive=False):
+    """tango/interfacegrids_gene.py:486-526."""
+    xI, xO = np.asarray(xIn, dtype=float), np.asarray(xOut, dtype=float)
+    out = np.zeros_like(xO)
+    lo = np.where(xO > xI[0])[0][0]
+    out[lo:] = spline_resample(xI, fIn, xO[lo:])
+    if enforce_positive:
+        out[out < 0] = 0
+    return out
+
+
+def extrap_on_left_and_right(xIn, fIn, xOut, inL, inR, outL, outR, degree, enforce_positive=False):
+    """tango/interfacegrids_gene.py:300-364: spline up to outR, fitted polynomials left of inL and right of outR."""
+    xI, fI, xO = np.asarray(xIn, dtype=float), np.asarray(fIn, dtype=float), np.asarray(xOut, dtype=float)
+    out = np.zeros_like(xO)
+    ind = (xO >= xI[0]) & (xO <= outR)
+    out[ind] = spline_resample(xI, fI, xO[ind])
+    z = (xI >= inL) & (xI <= inR)
+    out[xO < inL] = np.polyval(np.polyfit(xI[z], fI[z], degree), xO[xO < inL])
+    z = (xI >= outL) & (xI <= outR)
+    out[xO > outR] = np.polyval(np.polyfit(xI[z], fI[z], degree), xO[xO > outR])
+    if enforce_positive:
+        out[out < 0] = 0
+    return out
+
+
+def constrained_regression_line(x, y, xEval, side='right', numPts=10):
+    """tango/interfacegrids_gene.py:528-576: line through the end point with the least-squares slope of numPts points."""
+    x, y = np.asarray(x, dtype=float), np.asarray(y, dtype=float)
+    xs, ys, x0, y0 = (x[:numPts], y[:numPts], x[0], y[0]) if side == 'left' else (x[-numPts:], y[-numPts:], x[-1], y[-1])
+    a = np.dot(xs - x0, ys - y0) / np.dot(xs - x0, xs - x0)
+    return a * (np.asarray(xEval, dtype=float) - x0) + y0
+
+
+def truncate_on_left_extrapolate_on_right(xIn, fIn, xOut, numPts=10, enforce_positive=False, side='right'):
+    """tango/interfacegrids_gene.py:579-634: the regression line, replaced by the spline strictly inside xIn."""
+    xI, xO = np.asarray(xIn, dtype=float), np.asarray(xOut, dtype=float)
+    out = constrained_regression_line(xI, fIn, xO, side, numPts)
+    ind = (xO > xI[0]) & (xO < xI[-1])
+    out[ind] = spline_resample(xI, fIn, xO[ind])
+    if enforce_positive:
+        out[out < 0] = 0
+    return out
+
+
+def truncate_on_left_fixed_slope_on_right(xIn, fIn, xOut, slope, enforce_positive=False):
+    """tango/interfacegrids_gene.py:636-692: imposed slope outside xIn, spline on its closed range."""
+    xI, fI, xO = np.asarray(xIn, dtype=float), np.asarray(fIn, dtype=float), np.asarray(xOut, dtype=float)
+    out = np.zeros_like(xO)
+    out[xO < xI[0]] = slope * (xO[xO < xI[0]] - xI[0]) + fI[0]
+    out[xO > xI[-1]] = slope * (xO[xO > xI[-1]] - xI[-1]) + fI[-1]
+    ind = (xO >= xI[0]) & (xO <= xI[-1])
+    out[ind] = spline_resample(xI, fI, xO[ind])
+    if enforce_positive:
+        out[out < 0] = 0
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # synthetic ensembles of the benchmark configurations
 # --------------------------------------------------------------------------------------

@@ -427,6 +427,48 @@ def g16():
     save('g16_gridmap', **out)
 
 
+def g17():
+    """The remaining grid mappers (tango/interfacegrids_gene.py:181-245, :300-443, :528-692): extrapolation of the
+    coefficients at both boundaries, and the turbulence grid reaching beyond the outer end of the transport grid.
+    make_extrapolator_fixed_slope uses the alias numpy.float, which numpy 2 no longer has; it is put back (as the
+    builtin float, what it always was) for the duration of this function."""
+    from tango import interfacegrids_gene as ig
+    had = hasattr(np, 'float')
+    if not had:
+        np.float = float
+    try:
+        xT = np.linspace(0.0, 1.0, 60)
+        xG = np.linspace(0.13, 0.81, 150)
+        Dg = 0.3 * np.exp(-((xG - 0.45) / 0.2) ** 2) - 0.004
+        cg = 0.1 * np.sin(7 * xG) * (xG - 0.13) * (0.81 - xG)
+        prof = 1.2 - 0.7 * xT ** 2 + 0.05 * np.sin(9 * xT)
+        gb = ig.TangoOutsideExtrapCoeffsBothSides(xT, xG, 0.2, 0.32, 0.55, 0.7, 2)
+        out = dict(xT=xT, xG=xG, Dg=Dg, cg=cg, prof=prof, both_prof_on_G=gb.map_profile_onto_turb_grid(prof))
+        out['both_D_on_T'], out['both_c_on_T'] = gb.map_transport_coeffs_onto_transport_grid(Dg, cg)
+        # transport grid 0..0.8, turbulence grid 0.1..1: it ends beyond the transport grid
+        xTi = np.linspace(0.0, 0.8, 50)
+        xGi = np.linspace(0.1, 1.0, 140)
+        profi = 1.1 - 0.9 * xTi ** 2 + 0.03 * np.cos(11 * xTi)
+        steep = 2.0 - 2.6 * xTi                      # continued outward it turns negative: exercises enforcePositive
+        Dgi = 0.25 * np.exp(-((xGi - 0.5) / 0.25) ** 2) - 0.01
+        cgi = 0.08 * np.sin(6 * xGi) * (xGi - 0.1)
+        gi = ig.GridInterfaceTangoInside(xTi, xGi)
+        out.update(xTi=xTi, xGi=xGi, profi=profi, steep=steep, Dgi=Dgi, cgi=cgi,
+                   in_prof_on_G=gi.map_profile_onto_turb_grid(profi), in_steep_on_G=gi.map_profile_onto_turb_grid(steep))
+        out['in_D_on_T'], out['in_c_on_T'] = gi.map_transport_coeffs_onto_transport_grid(Dgi, cgi)
+        gf = ig.GridInterfaceTangoInsideFixedOutside(xTi, xGi, -1.7)
+        out['fix_prof_on_G'] = gf.map_profile_onto_turb_grid(profi)
+        out['fix_steep_on_G'] = gf.map_profile_onto_turb_grid(steep)
+        out['fix_D_on_T'], out['fix_c_on_T'] = gf.map_transport_coeffs_onto_transport_grid(Dgi, cgi)
+        out['slope'] = np.array(ig.least_squares_slope(xTi[-10:], profi[-10:], xTi[-1], profi[-1]))
+        out['reg_left'] = ig.extrap1d_constrained_linear_regression(xTi, profi, np.linspace(-0.2, 0.1, 7), side='left', numPts=6)
+        out['ext_left'] = ig.make_extrapolator(xTi, profi, 'left', 6)(np.linspace(-0.2, 0.5, 23))
+    finally:
+        if not had:
+            del np.float
+    save('g17_gridmap_more', **out)
+
+
 # ---------------------------------------------------------------- G9 three-field trajectories
 def run_ref_3f(N, nu0, BCs, a_turb, a_prof, tol, maxit, inner=0, dt=1e6, keep=()):
     dx = 1 / (N - 1); x = np.arange(N) * dx
@@ -518,6 +560,6 @@ def g11():
 
 
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16']
+    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17']
     for w in which:
         globals()[w]()

@@ -243,3 +243,39 @@ def test_solver_with_grid_mapper(tango, golden):
     assert relerr(s.profilesAllIterations['n'][2], g['run_it2']) < 1e-10
     assert relerr(s.profiles['n'], g['run_final']) < 1e-10
     assert relerr(lm._EWMATurbD._yEWMA_lminus1, g['run_DE']) < 1e-10
+
+
+def test_grid_mapping_more_golden(tango, golden):
+    """tango/interfacegrids_gene.py:181-245, :300-443, :528-692: coefficients extrapolated at both boundaries; a
+    turbulence grid that reaches beyond the transport grid (fitted and imposed outward slope); batched rows."""
+    g = golden('g17_gridmap_more')
+    ig = tango.interfacegrids_gene
+    gb = ig.TangoOutsideExtrapCoeffsBothSides(g['xT'], g['xG'], 0.2, 0.32, 0.55, 0.7, 2)
+    assert relerr(gb.map_profile_onto_turb_grid(g['prof']), g['both_prof_on_G']) < 1e-12
+    D, c = gb.map_transport_coeffs_onto_transport_grid(g['Dg'], g['cg'])
+    assert relerr(D, g['both_D_on_T']) < 1e-11 and relerr(c, g['both_c_on_T']) < 1e-11
+    D2, c2 = gb.map_transport_coeffs_onto_transport_grid(np.stack([g['Dg'], 2 * g['Dg']]), np.stack([g['cg'], -g['cg']]))
+    assert relerr(D2[0], g['both_D_on_T']) < 1e-11 and relerr(c2[1], -g['both_c_on_T']) < 1e-11
+    gi = ig.GridInterfaceTangoInside(g['xTi'], g['xGi'])
+    assert relerr(gi.map_profile_onto_turb_grid(g['profi']), g['in_prof_on_G']) < 1e-12
+    assert relerr(gi.map_profile_onto_turb_grid(g['steep']), g['in_steep_on_G']) < 1e-12
+    rows = gi.map_profile_onto_turb_grid(np.stack([g['profi'], g['steep']]))
+    assert relerr(rows[0], g['in_prof_on_G']) < 1e-12 and relerr(rows[1], g['in_steep_on_G']) < 1e-12
+    D, c = gi.map_transport_coeffs_onto_transport_grid(g['Dgi'], g['cgi'])
+    assert relerr(D, g['in_D_on_T']) < 1e-12 and relerr(c, g['in_c_on_T']) < 1e-12
+    assert np.array_equal(gi.get_x_transport_grid(), g['xTi']) and np.array_equal(gi.get_x_turbulence_grid(), g['xGi'])
+    gf = ig.GridInterfaceTangoInsideFixedOutside(g['xTi'], g['xGi'], -1.7)
+    assert relerr(gf.map_profile_onto_turb_grid(g['profi']), g['fix_prof_on_G']) < 1e-12
+    assert relerr(gf.map_profile_onto_turb_grid(g['steep']), g['fix_steep_on_G']) < 1e-12
+    rows = gf.map_profile_onto_turb_grid(np.stack([g['steep'], g['profi']]))
+    assert relerr(rows[0], g['fix_steep_on_G']) < 1e-12 and relerr(rows[1], g['fix_prof_on_G']) < 1e-12
+    D, c = gf.map_transport_coeffs_onto_transport_grid(g['Dgi'], g['cgi'])
+    assert relerr(D, g['fix_D_on_T']) < 1e-12 and relerr(c, g['fix_c_on_T']) < 1e-12
+    with pytest.raises(AssertionError):
+        ig.GridInterfaceTangoInsideFixedOutside(g['xTi'], g['xGi'], 0.5)
+    with pytest.raises(AssertionError):
+        ig.GridInterfaceTangoInside(g['xGi'], g['xTi'])
+    assert abs(ig.least_squares_slope(g['xTi'][-10:], g['profi'][-10:], g['xTi'][-1], g['profi'][-1]) - float(g['slope'])) < 1e-13
+    assert relerr(ig.extrap1d_constrained_linear_regression(g['xTi'], g['profi'], np.linspace(-0.2, 0.1, 7), side='left', numPts=6),
+                  g['reg_left']) < 1e-13
+    assert relerr(ig.make_extrapolator(g['xTi'], g['profi'], 'left', 6)(np.linspace(-0.2, 0.5, 23)), g['ext_left']) < 1e-12

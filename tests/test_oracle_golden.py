@@ -263,3 +263,23 @@ def test_g16_grid_mapping(golden):
     assert relerr(orc.extend_with_zeros_both_sides(g['xG'], g['Dg'], g['xT'], True), g['D_on_T']) < 1e-13
     assert relerr(orc.extend_with_zeros_both_sides(g['xG'], g['cg'], g['xT']), g['c_on_T']) < 1e-13
     assert np.all(g['D_on_T'] >= 0) and g['D_on_T'][0] == 0 and g['D_on_T'][-1] == 0
+
+
+def test_g17_grid_mapping_more(golden):
+    """Two-sided extrapolation of coefficients and the maps for a turbulence grid that reaches beyond the transport
+    grid (tango/interfacegrids_gene.py:181-245, :300-443, :528-692)."""
+    g = golden('g17_gridmap_more')
+    assert relerr(orc.spline_resample(g['xT'], g['prof'], g['xG']), g['both_prof_on_G']) < 1e-13
+    assert relerr(orc.extrap_on_left_and_right(g['xG'], g['Dg'], g['xT'], 0.2, 0.32, 0.55, 0.7, 2, True), g['both_D_on_T']) < 1e-12
+    assert relerr(orc.extrap_on_left_and_right(g['xG'], g['cg'], g['xT'], 0.2, 0.32, 0.55, 0.7, 2), g['both_c_on_T']) < 1e-12
+    assert relerr(orc.truncate_on_left_extrapolate_on_right(g['xTi'], g['profi'], g['xGi'], 10, True), g['in_prof_on_G']) < 1e-13
+    assert relerr(orc.truncate_on_left_extrapolate_on_right(g['xTi'], g['steep'], g['xGi'], 10, True), g['in_steep_on_G']) < 1e-13
+    assert np.any(g['in_steep_on_G'] == 0)          # the clamp is exercised
+    assert relerr(orc.extend_with_zeros_left_side(g['xGi'], g['Dgi'], g['xTi'], True), g['in_D_on_T']) < 1e-13
+    assert relerr(orc.extend_with_zeros_left_side(g['xGi'], g['cgi'], g['xTi']), g['in_c_on_T']) < 1e-13
+    assert relerr(orc.truncate_on_left_fixed_slope_on_right(g['xTi'], g['profi'], g['xGi'], -1.7, True), g['fix_prof_on_G']) < 1e-13
+    assert relerr(orc.truncate_on_left_fixed_slope_on_right(g['xTi'], g['steep'], g['xGi'], -1.7, True), g['fix_steep_on_G']) < 1e-13
+    assert np.array_equal(g['fix_D_on_T'], g['in_D_on_T']) and np.array_equal(g['fix_c_on_T'], g['in_c_on_T'])
+    assert relerr(orc.constrained_regression_line(g['xTi'], g['profi'], np.linspace(-0.2, 0.1, 7), 'left', 6), g['reg_left']) < 1e-13
+    assert relerr(orc.truncate_on_left_extrapolate_on_right(g['xTi'], g['profi'], np.linspace(-0.2, 0.5, 23), 6, False, 'left'),
+                  g['ext_left']) < 1e-13
