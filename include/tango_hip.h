@@ -200,6 +200,12 @@ typedef struct {
      * profiles take the one-workgroup-per-profile kernel, which is 2-4 times slower at those sizes. */
     void *work;
     size_t work_bytes;
+    /* Optional history of the iterates (profilesAllIterations of tango/solver.py:225-227): the profile that
+     * iteration number i of profile b produces (i = the profile's iteration count before the step) is also written to
+     * iterates[(i * nb + b) * n ..], for i < iterates_rows.  Works with any iters_per_launch; the segmented form is
+     * not used while it is set. */
+    double *iterates;
+    int64_t iterates_rows;
 } tg_params_1f;
 
 enum { TG_TREAD_MAX_HALVINGS = 64 };

@@ -1,6 +1,6 @@
 """Throughput of the fused kernels on every single-GPU configuration of the benchmark set, plus time to
 convergence with the per-profile masks on.  Prints one JSON line per measurement (HIP events on the launch
-stream).  usage: python scripts/bench_configs.py [c2] [metric] [c3] [c4] [conv]"""
+stream).  usage: python scripts/bench_configs.py [c1] [c2] [metric] [c3] [c4] [conv]"""
 import ctypes as C
 import json
 import os
@@ -92,6 +92,33 @@ def three_field(nb=16384, n=512, reps=24):
                       'converged': bool(s2.converged), 'iterations_min_max': [int(it.min()), int(it.max())]}), flush=True)
 
 
+def single_profile(n=500):
+    """The reference's own example (examples/shestakov_basic.py: one profile, N = 500, tol 1e-11) through the Solver
+    API: wall time to convergence, with the convergence test on the host every iteration and every 8 iterations."""
+    sh = tango.extras.shestakov_nonlinear_diffusion
+    dx = 1.0 / (n - 1)
+    x = np.arange(n) * dx
+    for k in (1, 8):
+        walls = []
+        for rep in range(3):
+            lm = tango.lodestro_method.lm(0.3, 1.0, {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10})
+            f = tango.multifield.Field(label='n', rightBC=1e-2, profile_mminus1=1 - 0.5 * x, compute_all_H=sh.ComputeAllH(1.0, 0.1),
+                                       lodestroMethod=lm)
+            tango.multifield.check_fields_initialize([f])
+            call = tango.multifield.ComputeAllHAllFields([f], tango.lodestro_method.TurbulenceHandler(dx, x, sh.AnalyticFluxModel(dx)))
+            s = tango.solver.Solver(1, x, np.array([0, 1e4]), 1000, 1e-11, call, [f], iterationsPerCheck=k)
+            assert s._fused is not None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            s.take_timestep()
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+        its = len(s.errHistoryFinal)
+        print(json.dumps({'config': 'c1 single profile through Solver (tol 1e-11)', 'profiles': 1, 'N': n, 'iterationsPerCheck': k,
+                          'iterations': its, 'wall_ms': round(min(walls) * 1e3, 3), 'us_per_iteration': round(min(walls) * 1e6 / its, 1),
+                          'converged': bool(s.converged)}), flush=True)
+
+
 def convergence(nb=65536, n=512, k=8):
     st = torch.cuda.current_stream().cuda_stream
     E = OneFieldEnsemble(shestakov_ensemble(nb, n), a_turb=0.3, a_prof=1.0, tol=1e-11, fixed_count=False, keep_err=False)
@@ -115,8 +142,10 @@ def convergence(nb=65536, n=512, k=8):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['c2', 'metric', 'c3', 'c4', 'conv']
+    what = sys.argv[1:] or ['c1', 'c2', 'metric', 'c3', 'c4', 'conv']
     H.set_stream(torch.cuda.current_stream().cuda_stream)
+    if 'c1' in what:
+        single_profile()
     if 'c2' in what:
         one_field('c2 one-field', 65536, 256, 1.0, (1, 8))
     if 'metric' in what:

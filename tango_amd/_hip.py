@@ -54,7 +54,8 @@ class Params1F(C.Structure):
                 ('smooth_window', C.c_int32), ('fixed_count', C.c_int32), ('frozen_turb', C.c_int32),
                 ('iters_per_launch', C.c_int32), ('pseudo_time', C.c_int32), ('tread_lightly', C.c_int32),
                 ('tread_inner_count', C.c_int32), ('tread_initial_steps', C.c_int32), ('reserved_', C.c_int32),
-                ('tread_max_change', _dbl), ('tread_initial_dtau', _dbl), ('work', _p), ('work_bytes', _sz)]
+                ('tread_max_change', _dbl), ('tread_initial_dtau', _dbl), ('work', _p), ('work_bytes', _sz),
+                ('iterates', _p), ('iterates_rows', _i64)]
 
 
 class State3F(C.Structure):

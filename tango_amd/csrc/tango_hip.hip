@@ -829,6 +829,8 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
 
         if (!done) {
             if (t == 0 && S_.err && it0 < S_.err_stride) S_.err[b * S_.err_stride + it0] = rms;
+            // history of the iterates (profilesAllIterations, tango/solver.py:225-227)
+            if (Q.iterates && it0 < Q.iterates_rows) store_chunk<P, FULL>(Q.iterates + ((int64_t)it0 * S_.nb + b) * S_.n, n, j0, u + 1);
             ++it0;
             if (!Q.frozen_turb) st |= TG_ST_SEEDED;
             if (!Q.fixed_count && rms < Q.tol) st |= TG_ST_CONVERGED;
@@ -906,7 +908,7 @@ struct Picard1fLauncher {
                        reinterpret_cast<uintptr_t>(st->cE) | reinterpret_cast<uintptr_t>(q->flux) |
                        reinterpret_cast<uintptr_t>(q->Vprime) | reinterpret_cast<uintptr_t>(q->gxx) |
                        reinterpret_cast<uintptr_t>(q->gradx) | reinterpret_cast<uintptr_t>(q->gxx_turb) |
-                       reinterpret_cast<uintptr_t>(q->gradx_turb);
+                       reinterpret_cast<uintptr_t>(q->gradx_turb) | reinterpret_cast<uintptr_t>(q->iterates);
         const bool full = (n == P * G::T) && (al & 15) == 0;
         const bool general = q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly;
         const bool multi = q->iters_per_launch > 1;
@@ -1105,6 +1107,7 @@ int tg_picard_1f_step(const tg_state_1f *st, const tg_params_1f *q, tg_stream st
         return fail(TG_ERR_ARG, "tread_initial_steps needs pseudo_time and tread_initial_dtau > 0%s");
     if (q->smooth_window > 1) return fail(TG_ERR_UNSUPPORTED, "flux smoothing is not fused; smooth the flux with tg_moving_average and pass it as an external flux%s");
     if (st->err && st->err_stride <= 0) return fail(TG_ERR_ARG, "err_stride must be positive%s");
+    if (q->iterates && q->iterates_rows < 0) return fail(TG_ERR_ARG, "iterates_rows must not be negative%s");
     if (st->nb == 0) return TG_OK;
     if (tg_seg_applies(st, q)) return tg_seg_step(st, q, S(stream));
     return dispatch_group<Picard1fLauncher, true>(st->nb, (int)st->n, S(stream), st, q);

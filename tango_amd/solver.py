@@ -483,18 +483,40 @@ class _Fused1F(object):
             H.check(H.lib.tg_memset(self.err.ptr, 0, self.err.nbytes, H.stream()))
         done = self.start = s.iterationNumber
         hist = s.profilesAllIterations
+        # The iterate history, when kept, is written by the kernel into a device buffer (tg_params_1f.iterates) and
+        # read back once at the end; a history beyond 256 MiB is streamed to the host iterate by iterate instead.
+        rows = s.maxIterations - done
+        snaps = None
+        if hist is not None and rows > 0 and rows * self.u.nbytes <= (256 << 20):
+            snaps = H.DeviceArray((rows, self.nb, self.n))
+            q.iterates, q.iterates_rows = snaps.ptr, rows
+        stream_hist = hist is not None and snaps is None
         while done < s.maxIterations:
-            k = 1 if hist is not None else min(s.iterationsPerCheck, s.maxIterations - done)
+            k = 1 if stream_hist else min(s.iterationsPerCheck, s.maxIterations - done)
             q.iters_per_launch = k        # k iterations in one launch, the profiles held in registers in between
             H.check(H.lib.tg_picard_1f_step(C.byref(self.state), C.byref(q), H.stream()))
             done += k
-            if hist is not None:
+            if stream_hist:
                 snap = self.u.to_host()
                 hist[self.label][done - 1 - self.start] = snap if s.batched else snap[0]
             H.check(H.lib.tg_status_reduce(self.status.ptr, self.nb, self.counts.ptr, H.stream()))
             active, conv, invalid, _ = (int(v) for v in self.counts.to_host())
             if active == 0:
                 break
+        if snaps is not None:
+            its = self.iters.to_host()
+            top = int(its.max())
+            got = np.empty((top, self.nb, self.n))      # only the rows that were written
+            if top:
+                H.check(H.lib.tg_copy_d2h(got.ctypes.data, snaps.ptr, got.nbytes, H.stream()))
+                H.check(H.lib.tg_stream_sync(H.stream()))
+            if s.batched:         # rows after a profile's last iteration repeat its final iterate
+                final = self.u.to_host()
+                late = np.arange(top)[:, None] >= its[None, :]
+                got[:top][late] = np.broadcast_to(final, (top,) + final.shape)[late]
+                hist[self.label][:top] = got[:top]
+            else:
+                hist[self.label][:top] = got[:top, 0]
         self.finish(s)
 
     def finish(self, s):

@@ -156,6 +156,37 @@ def test_ensemble32_matches_reference(tango, golden):
     assert same >= 24      # the great majority stop on the reference's iteration
 
 
+@pytest.mark.parametrize('N', [512, 300])
+def test_iterate_history_of_a_batch(tango, N):
+    """profilesAllIterations of a batch stepped several iterations per launch (the kernel writes the history) equals
+    the history of the same batch stepped one iteration per launch; rows after a profile's last iteration repeat its
+    final iterate."""
+    ens = orc.shestakov_ensemble(6, N)
+    runs = []
+    for k in (1, 5):
+        s, _ = make_solver(tango, N, ens['nL'], ens['S0'], ens['delta'], ens['u0'], 0.3, 1.0, 1e-9, 100, iterationsPerCheck=k,
+                           saveProfileHistory=True)
+        assert s._fused is not None and s.batched
+        s.take_timestep()
+        assert s.converged
+        runs.append(s)
+    a, b = runs
+    assert np.array_equal(a.iterationsPerProfile, b.iterationsPerProfile)
+    top = int(a.iterationsPerProfile.max())
+    assert a.profilesAllIterations['n'].shape == (top, 6, N) == b.profilesAllIterations['n'].shape
+    assert np.array_equal(a.profilesAllIterations['n'], b.profilesAllIterations['n'])
+    assert len(set(a.iterationsPerProfile.tolist())) > 1          # the members stop on different iterations
+    for m in range(6):
+        last = int(a.iterationsPerProfile[m])
+        assert np.array_equal(b.profilesAllIterations['n'][last - 1:, m], np.broadcast_to(b.profiles['n'][m], (top - last + 1, N)))
+        # one member alone gives the same rows
+    s1, _ = make_solver(tango, N, ens['nL'][2], ens['S0'][2], ens['delta'][2], ens['u0'][2], 0.3, 1.0, 1e-9, 100, iterationsPerCheck=3)
+    s1.take_timestep()
+    k2 = len(s1.errHistoryFinal)
+    assert k2 == int(a.iterationsPerProfile[2])
+    assert relerr(s1.profilesAllIterations['n'], b.profilesAllIterations['n'][:k2, 2]) < 1e-13
+
+
 @pytest.mark.parametrize('N', [40, 100, 300, 1000, 1024, 2048, 4096])
 def test_fused_step_other_sizes_vs_oracle(tango, N):
     """Ragged sizes (not a multiple of the 8-point lane chunk) and the multi-wavefront path (N > 512)."""
