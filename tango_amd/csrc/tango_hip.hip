@@ -447,10 +447,13 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     using Tile = WaveTile<8>;
     constexpr int NT = kCoopTiles<G>;
     Tile wt(lds + (COOP_T ? (G::kBlock ? 8 * G::T : 0) + (threadIdx.x >> 6) * NT * Tile::kDoubles : 0));
+    // The old EWMA memory of the profile has weight 1 - a_prof: with a_prof = 1 (and whenever the turbulence step is
+    // skipped) it is not read at all; zeros stand in, so that a_prof u + 0 * memory is u exactly.
+    const bool need_ue = !Q.frozen_turb && (external || Q.a_prof != 1.0);
     auto load_state_coop = [&]() {
         double2 r0[4], r1[4], r2[4], r3[4], r4[4];
         wt.fetch(S_.u + woff, r0);
-        wt.fetch(S_.uE + woff, r1);
+        if (need_ue) wt.fetch(S_.uE + woff, r1);
         wt.fetch(S_.DE + woff, r2);
         wt.fetch(S_.cE + woff, r3);
         wt.fetch(S_.um1 + woff, r4);
@@ -458,23 +461,27 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         if constexpr (GENERAL) {
             if (external) wt.fetch(Q.flux + woff, r5);
         }
+        if (!need_ue) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) ue[i] = 0.0;
+        }
         if constexpr (NT >= 4) {
             wt.stage(0, r0);
-            wt.stage(1, r1);
+            if (need_ue) wt.stage(1, r1);
             wt.stage(2, r2);
             wt.stage(3, r3);
             Tile::sync();
             wt.take(0, u + 1);
-            wt.take(1, ue);
+            if (need_ue) wt.take(1, ue);
             wt.take(2, DE);
             wt.take(3, cE);
             Tile::sync();
         } else {
             wt.stage(0, r0);
-            wt.stage(1, r1);
+            if (need_ue) wt.stage(1, r1);
             Tile::sync();
             wt.take(0, u + 1);
-            wt.take(1, ue);
+            if (need_ue) wt.take(1, ue);
             Tile::sync();
             wt.stage(0, r2);
             wt.stage(1, r3);
@@ -498,7 +505,12 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     };
     auto load_state_lane = [&]() {
         load_chunk<P, FULL>(S_.u + off, n, j0, u + 1, 0.0);
-        load_chunk<P, FULL>(S_.uE + off, n, j0, ue, 1.0);
+        if (need_ue) {
+            load_chunk<P, FULL>(S_.uE + off, n, j0, ue, 1.0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < P; ++i) ue[i] = 0.0;
+        }
         load_chunk<P, FULL>(S_.DE + off, n, j0, DE, 0.0);
         load_chunk<P, FULL>(S_.cE + off, n, j0, cE, 0.0);
         load_chunk<P, FULL>(S_.um1 + off, n, j0, um1, 0.0);
