@@ -89,14 +89,21 @@ struct WaveGroup {
     // dl_t = 1 + s_t + p_t (the row's diagonal-dominance slack) is carried along and every new diagonal is
     // formed as slack - s - p: for the M-matrices of the transport problem (s, p <= 0 <= dl) all those sums
     // have terms of one sign, so no cancellation eats the small slack as 1 - pm*s - sp*p would.
+    //
+    // No fill values for the lanes without a neighbour at distance h: the first lane has no left coupling (s = 0,
+    // enforced on entry) and by induction s = 0 in every lane t < h at the level of distance h (s2 = -sm s with
+    // sm taken from a lane below h), likewise p = 0 in the lanes t >= LPP - h.  Whatever those lanes fetch (the
+    // shuffles hand them their own, finite, values) is multiplied by an exact zero.
     template <bool FAST = false>
     __device__ double pcr(double s, double p, double dl, double r, int &singular) const {
+        s = (t_ == 0) ? 0.0 : s;
+        p = (t_ == LPP - 1) ? 0.0 : p;
 #pragma unroll
         for (int h = 1; h < LPP; h <<= 1) {
-            const double sm = from_left(s, h, 0.0), rm = from_left(r, h, 0.0);
-            const double dm = from_left(dl, h, 1.0);
-            const double pp = from_right(p, h, 0.0), rp = from_right(r, h, 0.0);
-            const double dp = from_right(dl, h, 1.0);
+            const double sm = __shfl_up(s, (unsigned)h, LPP), rm = __shfl_up(r, (unsigned)h, LPP);
+            const double dm = __shfl_up(dl, (unsigned)h, LPP);
+            const double pp = __shfl_down(p, (unsigned)h, LPP), rp = __shfl_down(r, (unsigned)h, LPP);
+            const double dp = __shfl_down(dl, (unsigned)h, LPP);
             const double d2 = dl - s * dm - p * dp;
             const double s2 = -(sm * s);
             const double p2 = -(pp * p);
