@@ -31,6 +31,14 @@ using namespace tg;
 // ------------------------------------------------------------------------------------------
 // Tridiagonal solve, point-fastest: one lane group per profile.
 // ------------------------------------------------------------------------------------------
+// rows can go through the coalesced path of tg_wave_io.h when a wavefront owns whole profiles, 512 points in all
+template <int P, class G, bool FULL>
+constexpr bool kWaveCoop = FULL && P == 8 && !(G::kBlock && G::T > 512);   // 1024 threads: no LDS left for tiles
+// LDS tiles per wavefront for that path: four, or two in a workgroup-per-profile kernel, whose exchange area shares
+// the LDS (four tiles there cost a resident workgroup per CU and measured slower)
+template <class G>
+constexpr int kCoopTiles = G::kBlock ? 2 : 4;
+
 template <int P, class G, bool FULL>
 __global__ void __launch_bounds__(G::kBlock ? G::T : 256)
 tridiag_pf_kernel(const double *__restrict__ A, const double *__restrict__ B, const double *__restrict__ C,
@@ -39,14 +47,53 @@ tridiag_pf_kernel(const double *__restrict__ A, const double *__restrict__ B, co
     extern __shared__ double lds[];
     G g(lds);
     const int64_t b = (int64_t)blockIdx.x * G::profiles_per_block(blockDim.x) + g.profile_in_block();
-    if (b >= nb) return;
+    // coalesced rows through the wavefront's LDS tiles when the wavefront owns 512 consecutive doubles of every array
+    // (one profile per wavefront or workgroup, or several short profiles that all exist)
+    constexpr bool COOP_T = kWaveCoop<P, G, FULL>;
+    constexpr bool COOP_ALWAYS = COOP_T && (G::kBlock || G::T == 64);
+    const bool exists = b < nb;
+    const bool coop = COOP_ALWAYS || (COOP_T && __all(exists));
+    if (!exists) return;
     const int j0 = g.t() * P;
     const int64_t off = b * (int64_t)n;
+    const int64_t woff = G::kBlock ? off + (int64_t)(threadIdx.x >> 6) * 512 : off - (int64_t)((threadIdx.x & 63) / G::T) * n;
+    using Tile = WaveTile<8>;
+    constexpr int NT = 2;      // two tiles per wavefront keep four wavefronts per SIMD resident
+    Tile wt(lds + (COOP_T ? (G::kBlock ? 8 * G::T : 0) + (threadIdx.x >> 6) * NT * Tile::kDoubles : 0));
     double a[P], bb[P], c[P], d[P];
-    load_chunk<P, FULL>(A + off, n, j0, a, 0.0);
-    load_chunk<P, FULL>(B + off, n, j0, bb, 1.0);
-    load_chunk<P, FULL>(C + off, n, j0, c, 0.0);
-    load_chunk<P, FULL>(D + off, n, j0, d, 0.0);
+    if (COOP_T && coop) {
+        double2 r0[4], r1[4], r2[4], r3[4];
+        wt.fetch(A + woff, r0);
+        wt.fetch(B + woff, r1);
+        wt.fetch(C + woff, r2);
+        wt.fetch(D + woff, r3);
+        wt.stage(0, r0);
+        wt.stage(1, r1);
+        if constexpr (NT >= 4) {
+            wt.stage(2, r2);
+            wt.stage(3, r3);
+        }
+        Tile::sync();
+        wt.take(0, a);
+        wt.take(1, bb);
+        if constexpr (NT >= 4) {
+            wt.take(2, c);
+            wt.take(3, d);
+        } else {
+            Tile::sync();
+            wt.stage(0, r2);
+            wt.stage(1, r3);
+            Tile::sync();
+            wt.take(0, c);
+            wt.take(1, d);
+        }
+        Tile::sync();
+    } else {
+        load_chunk<P, FULL>(A + off, n, j0, a, 0.0);
+        load_chunk<P, FULL>(B + off, n, j0, bb, 1.0);
+        load_chunk<P, FULL>(C + off, n, j0, c, 0.0);
+        load_chunk<P, FULL>(D + off, n, j0, d, 0.0);
+    }
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         c[i] = (j0 + i == 0) ? 0.0 : c[i];
@@ -54,7 +101,13 @@ tridiag_pf_kernel(const double *__restrict__ A, const double *__restrict__ B, co
     }
     int sing = 0;
     chunk_solve<P>(g, c, bb, a, d, sing);
-    store_chunk<P, FULL>(u + off, n, j0, d);
+    if (COOP_T && coop) {
+        wt.put(0, d);
+        Tile::sync();
+        wt.flush(0, u + woff);
+    } else {
+        store_chunk<P, FULL>(u + off, n, j0, d);
+    }
     if (status) {
         sing = g.any(sing);
         if (sing && g.t() == 0) atomicOr(&status[b], TG_ST_SINGULAR);
@@ -394,13 +447,6 @@ __global__ void status_reduce_kernel(const int32_t *__restrict__ status, int64_t
 // GENERAL = false is the Cartesian case with the built-in flux (no geometry arrays, no external flux): H2 and H3
 // are then the EWMA memories themselves and need no registers of their own.
 // MULTI = false compiles the single-iteration form (no loop, no selects on `done`).
-// rows can go through the coalesced path of tg_wave_io.h when a wavefront owns whole profiles, 512 points in all
-template <int P, class G, bool FULL>
-constexpr bool kWaveCoop = FULL && P == 8 && !(G::kBlock && G::T > 512);   // 1024 threads: no LDS left for tiles
-// LDS tiles per wavefront for that path: four, or two in a workgroup-per-profile kernel, whose exchange area shares
-// the LDS (four tiles there cost a resident workgroup per CU and measured slower)
-template <class G>
-constexpr int kCoopTiles = G::kBlock ? 2 : 4;
 
 template <int P, class G, bool FULL, bool GENERAL, bool MULTI>
 __global__ void __launch_bounds__(G::kBlock ? G::T : 256, (G::kBlock && G::T > 512) ? 4 : 2)   // two wavefronts per SIMD: <= 256 registers
@@ -903,6 +949,7 @@ struct TridiagLauncher {
         const bool full = (n == P * G::T) && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) |
                                                  reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(D) |
                                                  reinterpret_cast<uintptr_t>(u)) & 15) == 0;
+        if (kWaveCoop<P, G, true> && full) lds += (size_t)(block / 64) * 2 * WaveTile<8>::kDoubles * sizeof(double);
         if (full) hipLaunchKernelGGL((tridiag_pf_kernel<P, G, true>), dim3(grid), dim3(block), lds, s, A, B, C, D, u, nb, n, status);
         else hipLaunchKernelGGL((tridiag_pf_kernel<P, G, false>), dim3(grid), dim3(block), lds, s, A, B, C, D, u, nb, n, status);
         return launch_check();
