@@ -1,3 +1,4 @@
+"""Throughput of the standalone kernels (tridiagonal solve, EWMA, residual, flux split) at the benchmark sizes."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'scripts'))
 import numpy as np, torch
