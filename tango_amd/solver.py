@@ -43,7 +43,7 @@ class Solver(object):
                  useInnerIteration=False, innerIterationMaxCount=20,
                  user_control_func=None,
                  saveFluxesInMemory=False,
-                 iterationsPerCheck=1, saveProfileHistory=None):
+                 iterationsPerCheck=1, saveProfileHistory=None, detectStaticH=True):
         """Arguments up to saveFluxesInMemory are those of tango/solver.py:33-39.
 
         iterationsPerCheck  (fused path) iterations per kernel launch and between two host reads of the
@@ -52,6 +52,12 @@ class Solver(object):
                             iterations, which removes most of the HBM traffic.
         saveProfileHistory  keep profilesAllIterations (profiles x maxIterations x N values); default: only
                             for single-profile runs.
+        detectStaticH       one-field problems: find out by two trial calls (different profiles, first and last
+                            time) whether the field's compute_all_H callback contributes the same H1/H7 whatever
+                            the profiles and the time, as the callbacks of the example scripts do
+                            (examples/shestakov_basic.py:41-53); if so the iteration runs on the fused path with the
+                            flux model called on the host.  A callback can state the answer itself with an attribute
+                            static_H = True / False, which suppresses the trial calls.
         """
         self.L = L
         self.x = x
@@ -104,6 +110,7 @@ class Solver(object):
         self.numProfiles = first.shape[0] if self.batched else 1
         self.saveProfileHistory = (not self.batched) if saveProfileHistory is None else saveProfileHistory
         self.iterationsPerCheck = max(1, int(iterationsPerCheck))
+        self.detectStaticH = bool(detectStaticH)
 
         self.profilesAllTimesteps = {}
         self.fluxesAllTimesteps = {}
@@ -404,8 +411,10 @@ def _plan_fused(s):
     if one and model == 'shestakov' and not th.doSmoothing and not th.isNonCartesian and plain(s.fields[0].lodestroMethod._fluxSplitter) \
             and getattr(s.fields[0].compute_all_H, 'fused_source', None) is not None and th.fluxModel.dx == s.dx:
         return _Fused1F(s)
-    if one and getattr(s.fields[0].compute_all_H, 'static_H', False):
-        return _FusedExternal1F.plan(s)
+    if one and _callback_is_static(s):
+        plan = _FusedExternal1F.plan(s)
+        if plan is not None:
+            return plan
     if th.doSmoothing or th.isNonCartesian or not all(plain(f.lodestroMethod._fluxSplitter) for f in s.fields):
         return None
     if s.useTreadLightly or s.useTreadInitially:
@@ -414,6 +423,36 @@ def _plan_fused(s):
         from .extras import threefield
         return threefield.plan(s)
     return None
+
+
+def _callback_is_static(s):
+    """Does the one field's compute_all_H callback contribute coefficients that depend on x only?  Its attribute
+    static_H answers when present; otherwise (detectStaticH) the callback is called for the first and the last time of
+    tArray with two different sets of profiles and no turbulent coefficients, and the answer is yes when every
+    coefficient comes back bit for bit the same."""
+    f = s.fields[0]
+    cb = f.compute_all_H
+    flag = getattr(cb, 'static_H', None)
+    if flag is not None:
+        return bool(flag)
+    if not s.detectStaticH:
+        return False
+    try:
+        p0 = np.array(s.profiles[f.label], dtype=np.float64)
+        p1 = p0 * 1.37 + 0.11 * (1.0 + np.asarray(s.x, dtype=np.float64))
+        a = cb(s.tArray[0], s.x, {f.label: p0}, _mf.HCoefficients())
+        b = cb(s.tArray[-1], s.x, {f.label: p1}, _mf.HCoefficients())
+    except Exception:
+        return False
+    if not isinstance(a, _mf.HCoefficients) or not isinstance(b, _mf.HCoefficients):
+        return False
+    for k in ('H1', 'H2', 'H3', 'H4', 'H6', 'H7', 'H8'):
+        va, vb = getattr(a, k), getattr(b, k)
+        if (va is None) != (vb is None):
+            return False
+        if va is not None and not np.array_equal(np.asarray(va), np.asarray(vb)):
+            return False
+    return True
 
 
 class _Fused1F(object):
@@ -630,13 +669,13 @@ class _FusedExternal1F(_Fused1F):
         done = self.start = s.iterationNumber
         hist = s.profilesAllIterations
         pick = (lambda a: a) if s.batched else (lambda a: a[0])
+        u = self.u.to_host()
         while done < s.maxIterations:
             status = self.status.to_host()
             active = (status & (H.ST_CONVERGED | H.ST_INVALID)) == 0
             if not active.any():
                 break
             # host side of the protocol: EWMA of the profiles that still iterate, flux model, smoothing
-            u = self.u.to_host()
             if self.uE_host is None:
                 self.uE_host = u.copy()
             new = a_prof * u + (1 - a_prof) * self.uE_host
@@ -648,8 +687,9 @@ class _FusedExternal1F(_Fused1F):
             self.flux.set(np.atleast_2d(flux))
             H.check(H.lib.tg_picard_1f_step(C.byref(self.state), C.byref(q), H.stream()))
             done += 1
+            u = self.u.to_host()          # the new iterate: history row and input of the next profile EWMA
             if hist is not None:
-                hist[self.label][done - 1 - self.start] = pick(self.u.to_host())
+                hist[self.label][done - 1 - self.start] = pick(u)
                 if s.fluxesAllIterations is not None:
                     s.fluxesAllIterations[self.label][done - 1 - self.start] = flux
         self.finish(s)

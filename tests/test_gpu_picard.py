@@ -51,7 +51,9 @@ def make_solver(tango, N, nL, S0, delta, n0, a_turb, a_prof, tol, maxit, dt=1e4,
     lm = tango.lodestro_method.lm(a_turb, a_prof, th)
     if fused:
         cb = sh.ComputeAllH(S0, delta)
-    else:      # a plain user callback, as in examples/shestakov_basic.py:41-53 -> generic path
+    else:      # a plain user callback, as in examples/shestakov_basic.py:41-53, kept on the generic path
+        kw.setdefault('detectStaticH', False)
+
         def cb(t, xx, profiles, HT):
             return tango.multifield.HCoefficients(H1=np.ones_like(xx), H7=sh.GetSource(xx, S0, delta)) + HT
     f = tango.multifield.Field(label='n', rightBC=nL, profile_mminus1=n0, compute_all_H=cb, lodestroMethod=lm)
@@ -154,6 +156,55 @@ def test_ensemble32_matches_reference(tango, golden):
         assert np.all(s.errHistory[b, got:] == 0)
         assert relerr(s.profiles['n'][b], g['finals'][b]) < TOL
     assert same >= 24      # the great majority stop on the reference's iteration
+
+
+def test_example_script_callbacks_take_the_fused_path(tango, golden):
+    """examples/shestakov_basic.py as written: a flux-model class and a compute_all_H function defined by the script.
+    The callback's own coefficients turn out not to depend on profiles or time, so the run takes the fused path with
+    the script's flux model called on the host, and reproduces the reference's trajectory."""
+    g = golden('g8_onefield')
+    N = 500
+    dx = 1 / (N - 1); x = np.arange(N) * dx
+    sh = tango.extras.shestakov_nonlinear_diffusion
+    calls = []
+
+    class FluxModel(object):          # examples/shestakov_basic.py:55-66
+        def __init__(self, dx):
+            self.dx = dx
+
+        def get_flux(self, profiles):
+            calls.append(1)
+            return {'n': sh.get_flux(profiles['n'], self.dx)}
+
+    def compute_all_H(t, xx, profiles, HCoeffsTurb):          # examples/shestakov_basic.py:41-53, as a plain function
+        return tango.multifield.HCoefficients(H1=np.ones_like(xx), H7=sh.GetSource(xx)) + HCoeffsTurb
+
+    def build(cb, tArray=(0, 1e4), **kw):
+        lm = tango.lodestro_method.lm(0.3, 1.0, {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10})
+        f = tango.multifield.Field(label='n', rightBC=1e-2, profile_mminus1=1 - 0.5 * x, compute_all_H=cb, lodestroMethod=lm)
+        tango.multifield.check_fields_initialize([f])
+        call = tango.multifield.ComputeAllHAllFields([f], tango.lodestro_method.TurbulenceHandler(dx, x, FluxModel(dx)))
+        return tango.solver.Solver(1, x, np.array(tArray), 1000, 1e-11, call, [f], **kw)
+
+    s = build(compute_all_H)
+    assert type(s._fused).__name__ == '_FusedExternal1F'
+    s.take_timestep()
+    k = int(g['N500_p1_iters'])
+    assert s.converged and len(s.errHistoryFinal) == k and len(calls) == k
+    assert np.allclose(s.errHistoryFinal, g['N500_p1_err'], rtol=1e-6, atol=2e-12)
+    assert relerr(s.profiles['n'], g['N500_p1_final']) < TOL
+    assert relerr(s.profilesAllIterations['n'][10], g['N500_p1_it10_u']) < TOL
+    # detection off, or a callback that answers for itself: generic path
+    assert build(compute_all_H, detectStaticH=False)._fused is None
+    compute_all_H.static_H = False
+    assert build(compute_all_H)._fused is None
+    # callbacks whose own coefficients depend on the profile or on time stay on the generic path
+    def by_profile(t, xx, profiles, HT):
+        return tango.multifield.HCoefficients(H1=np.ones_like(xx), H7=sh.GetSource(xx) * profiles['n'][0]) + HT
+    def by_time(t, xx, profiles, HT):
+        return tango.multifield.HCoefficients(H1=np.ones_like(xx), H7=sh.GetSource(xx) * (1 + t)) + HT
+    assert build(by_profile)._fused is None
+    assert build(by_time)._fused is None
 
 
 @pytest.mark.parametrize('N', [512, 300])
@@ -385,7 +436,7 @@ def test_several_timesteps(tango, golden, fused):
     f = tango.multifield.Field(label='n', rightBC=1e-2, profile_mminus1=g['n0'].copy(), compute_all_H=cb, lodestroMethod=lm)
     tango.multifield.check_fields_initialize([f])
     call = tango.multifield.ComputeAllHAllFields([f], tango.lodestro_method.TurbulenceHandler(dx, x, sh.AnalyticFluxModel(dx)))
-    s = tango.solver.Solver(1, x, g['tArray'], 400, 1e-10, call, [f])
+    s = tango.solver.Solver(1, x, g['tArray'], 400, 1e-10, call, [f], detectStaticH=fused)
     assert (s._fused is not None) == fused
     m = 0
     while s.ok:
@@ -487,7 +538,8 @@ def test_python_flux_model_in_noncartesian_geometry(tango, golden, tag, fused):
     f = tango.multifield.Field(label='n', rightBC=0.05, profile_mminus1=1 - 0.6 * x,
                                compute_all_H=ComputeAllHGeom(tango, g['Vp'], g['S'], fused), lodestroMethod=lm)
     tango.multifield.check_fields_initialize([f])
-    s = tango.solver.Solver(1, x, np.array([0, 50.0]), 40 if sm else 600, 1e-10, tango.multifield.ComputeAllHAllFields([f], turb), [f])
+    s = tango.solver.Solver(1, x, np.array([0, 50.0]), 40 if sm else 600, 1e-10, tango.multifield.ComputeAllHAllFields([f], turb), [f],
+                            detectStaticH=fused)
     assert (s._fused is not None) == fused
     while s.ok:
         s.take_timestep()
