@@ -53,6 +53,10 @@ int tg_memset(void *ptr, int value, size_t bytes, tg_stream stream);
 int tg_copy_h2d(void *dst, const void *src_host, size_t bytes, tg_stream stream);
 int tg_copy_d2h(void *dst_host, const void *src, size_t bytes, tg_stream stream);
 int tg_copy_d2d(void *dst, const void *src, size_t bytes, tg_stream stream);
+/* rows x width_bytes from one pitched device array into another (e.g. the written columns of a history, packed
+ * before they cross PCIe) */
+int tg_copy_d2d_2d(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows,
+                   tg_stream stream);
 int tg_stream_create(tg_stream *stream);
 int tg_stream_destroy(tg_stream stream);
 int tg_stream_sync(tg_stream stream);

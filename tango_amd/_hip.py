@@ -81,6 +81,7 @@ PROTOTYPES = {
     'tg_copy_h2d': (_int, [_p, _p, _sz, _p]),
     'tg_copy_d2h': (_int, [_p, _p, _sz, _p]),
     'tg_copy_d2d': (_int, [_p, _p, _sz, _p]),
+    'tg_copy_d2d_2d': (_int, [_p, _sz, _p, _sz, _sz, _sz, _p]),
     'tg_stream_create': (_int, [C.POINTER(_p)]),
     'tg_stream_destroy': (_int, [_p]),
     'tg_stream_sync': (_int, [_p]),
@@ -175,6 +176,19 @@ class DeviceArray:
         check(lib.tg_copy_d2h(out.ctypes.data, self.ptr, self.nbytes, _stream))
         check(lib.tg_stream_sync(_stream))
         return out
+
+    def columns_to_host(self, k):
+        """The first k columns of a 2-D array as a C-contiguous host array (packed on the device first)."""
+        rows, cols = self.shape
+        k = max(0, min(int(k), cols))
+        if k == cols:
+            return self.to_host()
+        if k == 0:
+            return np.empty((rows, 0), self.dtype)
+        item = np.dtype(self.dtype).itemsize
+        packed = DeviceArray((rows, k), self.dtype)
+        check(lib.tg_copy_d2d_2d(packed.ptr, k * item, self.ptr, cols * item, k * item, rows, _stream))
+        return packed.to_host()
 
     def copy_from(self, other):
         assert other.nbytes == self.nbytes

@@ -1023,6 +1023,12 @@ int tg_memset(void *ptr, int value, size_t bytes, tg_stream stream) { TG_HIP(hip
 int tg_copy_h2d(void *dst, const void *src, size_t bytes, tg_stream stream) { TG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream))); return TG_OK; }
 int tg_copy_d2h(void *dst, const void *src, size_t bytes, tg_stream stream) { TG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(stream))); return TG_OK; }
 int tg_copy_d2d(void *dst, const void *src, size_t bytes, tg_stream stream) { TG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(stream))); return TG_OK; }
+int tg_copy_d2d_2d(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows, tg_stream stream) {
+    if (width_bytes > dst_pitch || width_bytes > src_pitch) return fail(TG_ERR_ARG, "row width exceeds a pitch%s");
+    if (width_bytes == 0 || rows == 0) return TG_OK;
+    TG_HIP(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyDeviceToDevice, S(stream)));
+    return TG_OK;
+}
 int tg_stream_create(tg_stream *stream) {
     if (!stream) return fail(TG_ERR_ARG, "stream is NULL%s");
     hipStream_t s;

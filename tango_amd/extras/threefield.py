@@ -176,7 +176,10 @@ class Fused3F(object):
         self.finish(s)
 
     def finish(self, s):
-        status, iters, err = self.status.to_host(), self.iters.to_host(), self.err.to_host()
+        status, iters = self.status.to_host(), self.iters.to_host()
+        top = int(iters.max()) if iters.size else 0
+        err = np.zeros(self.err.shape)                 # only the columns that were written cross PCIe
+        err[:, :top] = self.err.columns_to_host(top)
         s.iterationsPerProfile = iters.astype(np.int64)
         s.iterationNumber = int(iters.max())
         s.countStoredIterations = s.iterationNumber
@@ -187,5 +190,7 @@ class Fused3F(object):
         s.errHistory = err if s.batched else err[0].copy()
         s.profiles = {f.label: pick(d.to_host()) for f, d in zip(self.fields, self.u)}
         for k, f in enumerate(self.fields):
-            f.lodestroMethod.set_ewma_iterates(pick(self.uE[k].to_host()), pick(self.DE[k].to_host()),
-                                               pick(self.cE[k].to_host()))
+            if s.batched:      # an ensemble's memories stay on the device until someone reads them
+                f.lodestroMethod.set_ewma_iterates(self.uE[k].to_host, self.DE[k].to_host, self.cE[k].to_host)
+            else:
+                f.lodestroMethod.set_ewma_iterates(self.uE[k].to_host()[0], self.DE[k].to_host()[0], self.cE[k].to_host()[0])

@@ -16,7 +16,23 @@ class EWMA(object):
 
     def __init__(self, EWMAParam):
         self.EWMAParam = EWMAParam
-        self._yEWMA_lminus1 = None
+        self._value = None
+        self._fetch = None
+
+    # The memory y_bar_{l-1}.  The fused solver paths hand over a callable that reads it from the device; it is
+    # called the first time someone looks (an ensemble's memories are hundreds of megabytes that most runs never read).
+    @property
+    def _yEWMA_lminus1(self):
+        if self._fetch is not None:
+            self._value, self._fetch = self._fetch(), None
+        return self._value
+
+    @_yEWMA_lminus1.setter
+    def _yEWMA_lminus1(self, y):
+        if callable(y):
+            self._value, self._fetch = None, y
+        else:
+            self._value, self._fetch = y, None
 
     def next_ewma_iterate(self, y_l):
         if np.ndim(y_l) == 0:   # scalars: plain host arithmetic

@@ -561,7 +561,9 @@ class _Fused1F(object):
     def finish(self, s):
         status = self.status.to_host()
         iters = self.iters.to_host()
-        err = self.err.to_host()
+        top = int(iters.max()) if iters.size else 0
+        err = np.zeros(self.err.shape)                 # only the columns that were written cross PCIe
+        err[:, :top] = self.err.columns_to_host(top)
         u = self.u.to_host()
         s.iterationsPerProfile = iters.astype(np.int64)
         s.countStoredIterations = int(iters.max())
@@ -576,8 +578,10 @@ class _Fused1F(object):
             s.errHistory = err[0].copy()
             s.profiles = {self.label: u[0]}
         m = s.fields[0].lodestroMethod
-        pick = (lambda a: a) if s.batched else (lambda a: a[0])
-        m.set_ewma_iterates(pick(self.uE.to_host()), pick(self.DE.to_host()), pick(self.cE.to_host()))
+        if s.batched:      # an ensemble's memories stay on the device until someone reads them
+            m.set_ewma_iterates(self.uE.to_host, self.DE.to_host, self.cE.to_host)
+        else:
+            m.set_ewma_iterates(self.uE.to_host()[0], self.DE.to_host()[0], self.cE.to_host()[0])
 
 
 class _FusedExternal1F(_Fused1F):
