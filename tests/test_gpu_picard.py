@@ -273,6 +273,72 @@ def test_fine_grid_vs_reference(tango, golden):
     assert np.allclose(E.err.to_host()[0], g['N8192_err'], rtol=1e-4)
 
 
+@pytest.mark.parametrize('seed', range(16))
+def test_random_problems_vs_oracle(tango, seed):
+    """Randomly drawn grids, timesteps, EWMA parameters, theta parameters (so that every branch of the theta rule and
+    of the upwinding weight occurs), sources and initial profiles, several iterations per launch or one: the fused
+    kernel against the CPU oracle, member by member.  Many of these problems are violent (first iterates that
+    overshoot by orders of magnitude, diffusivities spanning ten decades along a profile), so the bar for a member
+    is the parity bar or, where larger, a multiple of the oracle's own response to a rounding-level (1e-15)
+    perturbation of its initial profile."""
+    from tango_amd.ensemble import OneFieldEnsemble
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([9, 24, 64, 100, 255, 256, 300, 500, 512, 640, 1024]))
+    nb = int(rng.integers(1, 9))
+    its = int(rng.integers(3, 9))
+    k = int(rng.choice([1, 1, 3, 8]))
+    dt = float(10 ** rng.uniform(-1, 5))
+    a_turb, a_prof = float(rng.uniform(0.05, 1.0)), float(rng.choice([1.0, rng.uniform(0.05, 1.0)]))
+    theta = dict(Dmin=float(10 ** rng.uniform(-6, -1)), Dmax=float(10 ** rng.uniform(0, 13)), dpdxThreshold=float(10 ** rng.uniform(-1, 1.5)))
+    x = np.linspace(0, 1, N); dx = x[1] - x[0]
+    physical = seed % 2 == 0
+    if physical:      # the benchmark's family of problems with gentle relaxation: these must meet the plain parity bar
+        ens = orc.shestakov_ensemble(nb + 1, N, seed=seed)
+        ens = {key: (v[1:] if key in ('u0', 'nL', 'S0', 'delta') else v) for key, v in ens.items()}
+        u0 = ens['u0']
+        a_turb = float(rng.uniform(0.1, 0.4))
+        dt = float(10 ** rng.uniform(0, 5))
+    else:
+        a = rng.uniform(0.5, 2.0, nb)
+        u0 = a[:, None] * (1 - rng.uniform(0.2, 0.8, nb)[:, None] * x[None, :] ** rng.uniform(0.7, 2.0, nb)[:, None]) \
+            + 0.02 * rng.uniform(0, 1, nb)[:, None] * np.sin(7 * x)[None, :]
+        ens = dict(x=x, dx=dx, u0=u0, nL=u0[:, -1] * rng.uniform(0.5, 1.0, nb), S0=rng.uniform(0.2, 3.0, nb), delta=rng.uniform(0.05, 0.5, nb))
+    E = OneFieldEnsemble(ens, dt=dt, a_turb=a_turb, a_prof=a_prof, theta=theta, max_iter=its, fixed_count=True)
+    done = 0
+    while done < its:
+        kk = min(k, its - done)
+        E.step(iters=kk)
+        done += kk
+    u, DE, err, status = E.u.to_host(), E.DE.to_host(), E.err.to_host(), E.status.to_host()
+    H7 = orc.shestakov_source(x, ens['S0'], ens['delta'])
+
+    def oracle_run(start, b):
+        st = orc.State1F(start)
+        rms, bad = [], False
+        for _ in range(its):
+            r, inv = orc.picard_step_1f(st, dt, dx, ens['nL'][b], np.ones(N), H7[b], a_turb, a_prof, theta=theta)
+            rms.append(r)
+            bad = bad or bool(inv) or not np.all(np.isfinite(st.u))
+        return st, np.array(rms), bad
+
+    tame = 0
+    for b in range(nb):
+        st, rms, bad = oracle_run(u0[b], b)
+        st2, rms2, bad2 = oracle_run(u0[b] * (1 + 1e-15 * rng.standard_normal(N)), b)
+        if bad or bad2:
+            assert bad2 or status[b] & 2, (seed, b)        # the kernel flags what the reference flags
+            continue
+        sens = max(relerr(st2.u, st.u), relerr(st2.DE, st.DE))
+        bar = TOL if N <= 512 else 3e-10
+        if not physical:
+            bar = max(bar, 100 * sens)
+        tame += bar <= 3e-10
+        assert relerr(u[b], st.u) < bar, (seed, b, N, dt, sens)
+        assert relerr(DE[b], st.DE) < bar, (seed, b, N, dt, sens)
+        assert np.allclose(err[b, :its], rms, rtol=max(1e-6, 100 * sens), atol=1e-11), (seed, b)
+    assert tame == nb or not physical
+
+
 def test_full_size_properties(tango):
     """65 536 x 512 (the benchmark size): batch independence, permutation invariance and consistency of the
     new profile with the assembled system, checked without a CPU run of the whole ensemble."""
