@@ -485,25 +485,33 @@ def test_pseudo_timestep_control_ensemble(tango, golden):
     assert len(set(halvings)) > 2 and max(halvings) > 10     # the members really took different paths
 
 
-@pytest.mark.parametrize('fused', [True, False])
+@pytest.mark.parametrize('fused', [True, 'host flux', False])
 def test_several_timesteps(tango, golden, fused):
-    """tArray with four timesteps of unequal length: u_{m-1} and the EWMA memories carry over (tango/solver.py:117-186)."""
+    """tArray with four timesteps of unequal length: u_{m-1} and the EWMA memories carry over (tango/solver.py:117-186).
+    On the built-in fused path, on the fused path with the flux model called on the host (a script's own callback and
+    flux class), and on the generic path."""
     g = golden('g13_timesteps')
     N = int(g['N'])
     dx = 1 / (N - 1); x = np.arange(N) * dx
     th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
     sh = tango.extras.shestakov_nonlinear_diffusion
     lm = tango.lodestro_method.lm(0.3, 1.0, th)
-    if fused:
+    if fused is True:
         cb = sh.ComputeAllH(1.0, 0.1)
     else:
         def cb(t, xx, profiles, HT):
             return tango.multifield.HCoefficients(H1=np.ones_like(xx), H7=sh.GetSource(xx, 1.0, 0.1)) + HT
+
+    class ScriptFluxModel(object):
+        def get_flux(self, profiles):
+            return {'n': sh.get_flux(profiles['n'], dx)}
+
+    model = ScriptFluxModel() if fused == 'host flux' else sh.AnalyticFluxModel(dx)
     f = tango.multifield.Field(label='n', rightBC=1e-2, profile_mminus1=g['n0'].copy(), compute_all_H=cb, lodestroMethod=lm)
     tango.multifield.check_fields_initialize([f])
-    call = tango.multifield.ComputeAllHAllFields([f], tango.lodestro_method.TurbulenceHandler(dx, x, sh.AnalyticFluxModel(dx)))
-    s = tango.solver.Solver(1, x, g['tArray'], 400, 1e-10, call, [f], detectStaticH=fused)
-    assert (s._fused is not None) == fused
+    call = tango.multifield.ComputeAllHAllFields([f], tango.lodestro_method.TurbulenceHandler(dx, x, model))
+    s = tango.solver.Solver(1, x, g['tArray'], 400, 1e-10, call, [f], detectStaticH=bool(fused))
+    assert type(s._fused).__name__ == {True: '_Fused1F', 'host flux': '_FusedExternal1F', False: 'NoneType'}[fused]
     m = 0
     while s.ok:
         s.take_timestep()
