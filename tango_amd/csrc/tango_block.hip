@@ -163,6 +163,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     const double omp = 1.0 - Q.a_prof, omt = 1.0 - Q.a_turb;
     // grids of more than 512 points keep the reference's divisions (see tg_assemble.h)
     constexpr bool EXACT = (G::T * P > 512);
+    constexpr int DIV = EXACT ? kDivRounded : kDivFast;      // pivots: correctly rounded reciprocals on those grids
 
     constexpr bool COOP = FULL && (P == 4 || P == 8) && (G::kBlock || G::T == 64);
     using Tile = WaveTile<(P == 8) ? 8 : 4>;
@@ -249,12 +250,12 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             for (int s = 0; s < 3; ++s) dd[s] = ddx_edge1_point<EXACT>(ue[s][i], ue[s][i + 1], ue[s][i + 2], first, last, rc);
             const double pi = ue[1][i + 1];
             if constexpr (EXACT) {
-                const double Dsh = (dd[1] * dd[1]) / (pi * pi);     // D = (dpi/dx)^2 / pi^2, shared by the three fluxes
+                const double Dsh = quot<DIV>(dd[1] * dd[1], pi * pi);     // D = (dpi/dx)^2 / pi^2, shared by the three fluxes
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
                     const double flux = -Dsh * dd[s];
                     double D, c, DH, cH, thv;
-                    flux_split_point(flux, ue[s][i + 1], dd[s], 1.0, 1.0, th, D, c, DH, cH, thv);
+                    flux_split_point<DIV>(flux, ue[s][i + 1], dd[s], 1.0, 1.0, th, D, c, DH, cH, thv);
                     DE[s][i] = Q.a_turb * D + omt * (seeded ? DE[s][i] : D);
                     cE[s][i] = Q.a_turb * c + omt * (seeded ? cE[s][i] : c);
                 }
@@ -337,8 +338,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) UL[s] = Q.UL[s][b];
 
-    ChunkElim<P, !EXACT> eln;
-    BlockElim<2, P, !EXACT> elp;
+    ChunkElim<P, DIV> eln;
+    BlockElim<2, P, DIV> elp;
     double hm2[3], hm3[3], bm[3], h2c[3], h3c[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -346,7 +347,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         h3c[s] = -cE[s][0];
         hm2[s] = lane_first ? 0.0 : (h2l[s] + h2c[s]) / 2.0;
         hm3[s] = lane_first ? 0.0 : (h3l[s] + h3c[s]) / 2.0;
-        bm[s] = fbeta_point<!EXACT>(hm2[s], hm3[s], rc.dx);
+        bm[s] = fbeta_point<DIV>(hm2[s], hm3[s], rc.dx);
     }
     double mx[3] = {0.0, 0.0, 0.0}, ss[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -356,8 +357,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         const bool last = (j == n - 1);
         const int jc = valid ? j : n - 1;
         // collisional coupling nu = nu0 / ((pi + pe)/n)^{3/2} from the current profiles (example :108-110)
-        const double q = quot<!EXACT>(u[1][i + 1], u[0][i + 1]) + quot<!EXACT>(u[2][i + 1], u[0][i + 1]);
-        const double nu = quot<!EXACT>(nu0, q * sqrt(q));
+        const double q = quot<DIV>(u[1][i + 1], u[0][i + 1]) + quot<DIV>(u[2][i + 1], u[0][i + 1]);
+        const double nu = quot<DIV>(nu0, q * sqrt(q));
         double A[3], B[3], C[3], f[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -365,7 +366,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             const double h3n = (i == P - 1) ? h3r[s] : -cE[s][i < P - 1 ? i + 1 : 0];
             const double hp2 = (h2c[s] + h2n) / 2.0;
             const double hp3 = (h3c[s] + h3n) / 2.0;
-            const double bp = fbeta_point<!EXACT>(hp2, hp3, rc.dx);
+            const double bp = fbeta_point<DIV>(hp2, hp3, rc.dx);
             const double h6 = (s == 0) ? 0.0 : -nu;       // H6 = -nu for pi and pe (example :125, :144)
             fd_row<EXACT>(last, 1.0, um1[s][i], rc, UL[s], hm2[s], hm3[s], bm[s], hp2, hp3, bp, 0.0, h6, Q.H7[s][jc], A[s], B[s],
                          C[s], f[s]);

@@ -476,6 +476,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     const bool lane_first = (t == 0);
     // grids beyond one wavefront (n > 512) have condition numbers above 1e9: keep the reference's divisions
     constexpr bool EXACT = G::kBlock;
+    constexpr int DIV = EXACT ? kDivRounded : kDivFast;      // pivots: correctly rounded reciprocals on those grids
     const bool external = GENERAL && (Q.flux_model == TG_FLUX_EXTERNAL);
     const bool geom = GENERAL && (Q.Vprime != nullptr);
     const int iters = MULTI ? (Q.iters_per_launch > 1 ? Q.iters_per_launch : 1) : 1;
@@ -699,7 +700,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                 double D, c;
                 if constexpr (GENERAL || EXACT) {
                     // flux model (tango/extras/shestakov_nonlinear_diffusion.py:59-60)
-                    double flux = -(dpdx * dpdx * dpdx) / (p * p);
+                    double flux = quot<DIV>(-(dpdx * dpdx * dpdx), p * p);
                     double gx = 1.0, gr = 1.0;
                     if constexpr (GENERAL) {
                         flux = external ? fl[i] : flux;
@@ -707,7 +708,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                         gr = Q.gradx_turb ? grt[i] : 1.0;
                     }
                     double DH, cH, thv;
-                    flux_split_point(flux, p, dpdx, gx, gr, th, D, c, DH, cH, thv);
+                    flux_split_point<DIV>(flux, p, dpdx, gx, gr, th, D, c, DH, cH, thv);
                 } else {
                     shestakov_split_point(p, dpdx, th, D, c);   // built-in flux, Cartesian: one quotient
                 }
@@ -805,10 +806,10 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         double dtau = dt_full;
 #pragma unroll 1
         for (int attempt = 0;; ++attempt) {
-        ChunkElim<P, !EXACT> el;
+        ChunkElim<P, DIV> el;
         double hm2 = lane_first ? 0.0 : (h2l + h2first) / 2.0;
         double hm3 = lane_first ? 0.0 : (h3l + h3first) / 2.0;
-        double bm = fbeta_point<!EXACT>(hm2, hm3, rc.dx);
+        double bm = fbeta_point<DIV>(hm2, hm3, rc.dx);
         double mx = 0.0, ss = 0.0;
         double h2c = h2first, h3c = h3first;
 #pragma unroll
@@ -821,7 +822,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             const double h3n = (i == P - 1) ? h3r : H3at(i < P - 1 ? i + 1 : 0);
             const double hp2 = (h2c + h2n) / 2.0;
             const double hp3 = (h3c + h3n) / 2.0;
-            const double bp = fbeta_point<!EXACT>(hp2, hp3, rc.dx);
+            const double bp = fbeta_point<DIV>(hp2, hp3, rc.dx);
             const double H1 = Q.H1 ? Q.H1[jc] : 1.0;
             const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + jc] : ((j < src_cut) ? S0 : 0.0);
             double A, B, C, f;
@@ -847,7 +848,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         if (attempt == 0) {
             mx = g.max(mx);
             ss = g.sum(ss);
-            rms = sqrt(1.0 / (double)n * quot<!EXACT>(ss, mx * mx));
+            rms = sqrt(1.0 / (double)n * quot<DIV>(ss, mx * mx));
         }
 
         double xt[P];

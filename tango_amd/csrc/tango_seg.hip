@@ -180,9 +180,9 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
 
         auto split = [&](double pm, double p, double pp, bool first, bool last, double &D, double &c) {
             const double dpdx = ddx_edge1_point<EXACT>(pm, p, pp, first, last, rc);
-            const double flux = -(dpdx * dpdx * dpdx) / (p * p);   // tango/extras/shestakov_nonlinear_diffusion.py:59-60
+            const double flux = quot<kDivRounded>(-(dpdx * dpdx * dpdx), p * p);   // tango/extras/shestakov_nonlinear_diffusion.py:59-60
             double DH, cH, thv;
-            flux_split_point(flux, p, dpdx, 1.0, 1.0, th, D, c, DH, cH, thv);
+            flux_split_point<kDivRounded>(flux, p, dpdx, 1.0, 1.0, th, D, c, DH, cH, thv);
         };
         if (turb) {
 #pragma unroll
@@ -258,10 +258,10 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
     }
 
     // assemble and eliminate (tango/HToMatrixFD.py:87-117 row by row, as in picard_1f_kernel)
-    ChunkElim<P, false> el;
+    ChunkElim<P, kDivRounded> el;
     double hm2 = first_lane ? 0.0 : (h2l + DE[0]) / 2.0;
     double hm3 = first_lane ? 0.0 : (h3l - cE[0]) / 2.0;
-    double bm = fbeta_point<false>(hm2, hm3, rc.dx);
+    double bm = fbeta_point<kDivRounded>(hm2, hm3, rc.dx);
     double mx = 0.0, ss = 0.0;
     double h2c = DE[0], h3c = -cE[0];
 #pragma unroll
@@ -272,7 +272,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
         const double h3n = (i == P - 1) ? h3r : -cE[i < P - 1 ? i + 1 : 0];
         const double hp2 = (h2c + h2n) / 2.0;
         const double hp3 = (h3c + h3n) / 2.0;
-        const double bp = fbeta_point<false>(hp2, hp3, rc.dx);
+        const double bp = fbeta_point<kDivRounded>(hp2, hp3, rc.dx);
         const double H1 = Q.H1 ? Q.H1[j] : 1.0;
         const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + j] : ((j < src_cut) ? S0 : 0.0);
         double A, B, C, f;
@@ -367,7 +367,7 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
         return;
     }
     const int t = g.t();
-    ChunkElim<P, false> el;
+    ChunkElim<P, kDivRounded> el;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int r = t * P + i;

@@ -45,7 +45,7 @@ struct Theta {
 // does.  quot<true> qualifies: it is the arithmetic of the compiler's own IEEE division sequence (reciprocal
 // estimate, two Newton steps, quotient, residual correction) without that sequence's operand scaling and special-case
 // fix-up, which are no-ops for Dmax - DHat and Dmax - Dmin.
-template <bool FAST = false>
+template <int FAST = 0>
 __device__ __forceinline__ double theta_point(double dh, double dpdx, const Theta &th) {
     const bool small = fabs(dpdx) < th.thr;
     const double mid = (1.0 + quot<FAST>(th.Dmax - dh, th.span)) / 2.0;
@@ -57,22 +57,23 @@ __device__ __forceinline__ double theta_point(double dh, double dpdx, const Thet
 }
 
 // tango/lodestro_method.py:624-634 (DHat, cHat, D, c).
-// gxx / gradx are the geometric factors on the turbulence grid (1 in Cartesian geometry).
+// gxx / gradx are the geometric factors on the turbulence grid (1 in Cartesian geometry).  MODE: see quot (tg_comm.h).
+template <int MODE = 0>
 __device__ __forceinline__ void flux_split_point(double flux, double p, double dpdx, double gxx, double gradx,
                                                  const Theta &th, double &D, double &c, double &DHat,
                                                  double &cHat, double &theta) {
-    double dh = -flux / (gxx * dpdx);
+    double dh = quot<MODE>(-flux, gxx * dpdx);
     dh = (dpdx == 0.0) ? 0.0 : dh;
     DHat = dh;
-    cHat = flux / (gradx * p);
-    const double tv = theta_point(dh, dpdx, th);
+    cHat = quot<MODE>(flux, gradx * p);
+    const double tv = theta_point<MODE>(dh, dpdx, th);
     theta = tv;
     D = tv * dh;
     c = (1.0 - tv) * cHat;
 }
 
 // D = theta DHat, c = (1 - theta) cHat (tango/lodestro_method.py:631-634) from DHat and cHat formed by the caller
-template <bool FAST = false>
+template <int FAST = 0>
 __device__ __forceinline__ void split_from_hats(double dh, double cHat, double dpdx, const Theta &th, double &D, double &c) {
     const double tv = theta_point<FAST>(dh, dpdx, th);
     D = tv * dh;
@@ -91,7 +92,7 @@ __device__ __forceinline__ void shestakov_split_point(double p, double dpdx, con
 
 // tango/HToMatrixFD.py:277-297: adaptive upwinding weight at a half-integer grid point.
 // One division H2h/(c dx) serves both signs of c; the result is discarded where c == 0.
-template <bool FAST = false>
+template <int FAST = 0>
 __device__ __forceinline__ double fbeta_point(double H2h, double H3h, double dx) {
     const double gamma = 0.9;
     const double c = -H3h;

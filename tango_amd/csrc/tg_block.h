@@ -127,14 +127,14 @@ __device__ __forceinline__ void diag_from_rowsum(Mat<K> &G, const Vec<K> &rs) {
     }
 }
 
-template <bool FAST = false>
+template <int FAST = 0>
 __device__ __forceinline__ Mat<1> inverse(const Mat<1> &x, int &singular) {
     singular |= (x.m[0][0] == 0.0);
     Mat<1> r;
     r.m[0][0] = recip<FAST>(x.m[0][0]);
     return r;
 }
-template <bool FAST = false>
+template <int FAST = 0>
 __device__ __forceinline__ Mat<2> inverse(const Mat<2> &x, int &singular) {
     const double det = x.m[0][0] * x.m[1][1] - x.m[0][1] * x.m[1][0];
     singular |= (det == 0.0);
@@ -146,7 +146,7 @@ __device__ __forceinline__ Mat<2> inverse(const Mat<2> &x, int &singular) {
     r.m[1][1] = x.m[0][0] * inv;
     return r;
 }
-template <bool FAST = false>
+template <int FAST = 0>
 __device__ __forceinline__ Mat<3> inverse(const Mat<3> &x, int &singular) {
     const double c00 = x.m[1][1] * x.m[2][2] - x.m[1][2] * x.m[2][1];
     const double c01 = x.m[1][2] * x.m[2][0] - x.m[1][0] * x.m[2][2];
@@ -204,7 +204,7 @@ struct RowPack {
 
 // Block parallel cyclic reduction of S_t y_{t-h} + y_t + P_t y_{t+h} = r_t over the T lanes of group g.
 // dl_t = (S_t + I + P_t) 1 is the slack vector of the row, carried as in the scalar reduction.
-template <int K, bool FAST = false, class G>
+template <int K, int FAST = 0, class G>
 __device__ __forceinline__ Vec<K> block_pcr(const G &g, Mat<K> S, Mat<K> Pm, Vec<K> dl, Vec<K> r, int &singular) {
 #pragma unroll 1
     for (int h = 1; h < G::T; h <<= 1) {
@@ -233,8 +233,8 @@ __device__ __forceinline__ Vec<K> block_pcr(const G &g, Mat<K> S, Mat<K> Pm, Vec
     return r;
 }
 
-// FAST: reciprocals of the determinants by recip<true> (tg_comm.h).
-template <int K, int P, bool FAST = false>
+// FAST: the division mode of the determinants' reciprocals (tg_comm.h: kDivIeee, kDivFast, kDivRounded).
+template <int K, int P, int FAST = 0>
 struct BlockElim {
     Mat<K> E[P], L[P];
     Vec<K> f[P], rho[P];     // rho_i = (I + E_i + L_i) 1, the slack vector of the eliminated row

@@ -14,26 +14,35 @@
 namespace tg {
 
 // 1 / d and n / d without the scaling and fix-up steps of the IEEE sequence (12 issue slots -> 5 and 8): the
-// hardware estimate refined by two Newton steps, and one residual correction for the quotient.  Results are within
-// an ulp of the rounded ones as long as d and the quotient are normal numbers far from the exponent limits, which
-// holds for every divisor of the transport problem; a zero, infinite or NaN divisor gives NaN or infinity where
-// the true division would, so validity checks downstream see the same thing.  FAST = false is the division itself.
-template <bool FAST>
+// hardware estimate refined by two Newton steps, and one residual correction for the quotient.  The quotient is the
+// arithmetic of the compiler's own division sequence, so it is the correctly rounded one as long as d and the
+// quotient are normal numbers far from the exponent limits, which holds for every divisor of the transport problem;
+// the reciprocal without the last correction is within an ulp of it.  A zero, infinite or NaN divisor gives NaN or
+// infinity where the true division would, so validity checks downstream see the same thing.
+// MODE 0 is the division itself (standalone kernels: arbitrary operands); MODE 1 the short forms (reciprocal within
+// an ulp); MODE 2 the short forms with the reciprocal taken as the quotient 1/d, i.e. correctly rounded (grids of more
+// than 512 points, whose condition numbers above 1e9 leave no room for an extra ulp in the pivots).
+enum { kDivIeee = 0, kDivFast = 1, kDivRounded = 2 };
+template <int MODE>
+__device__ __forceinline__ double quot(double n, double d);
+template <int MODE>
 __device__ __forceinline__ double recip(double d) {
-    if constexpr (FAST) {
+    if constexpr (MODE == kDivFast) {
         double x = __builtin_amdgcn_rcp(d);
         double e = __builtin_fma(-d, x, 1.0);
         x = __builtin_fma(x, e, x);
         e = __builtin_fma(-d, x, 1.0);
         return __builtin_fma(x, e, x);
+    } else if constexpr (MODE == kDivRounded) {
+        return quot<kDivFast>(1.0, d);
     } else {
         return 1.0 / d;
     }
 }
-template <bool FAST>
+template <int MODE>
 __device__ __forceinline__ double quot(double n, double d) {
-    if constexpr (FAST) {
-        const double x = recip<true>(d);
+    if constexpr (MODE != kDivIeee) {
+        const double x = recip<kDivFast>(d);
         const double q = n * x;
         return __builtin_fma(__builtin_fma(-d, q, n), x, q);
     } else {
@@ -94,7 +103,7 @@ struct WaveGroup {
     // enforced on entry) and by induction s = 0 in every lane t < h at the level of distance h (s2 = -sm s with
     // sm taken from a lane below h), likewise p = 0 in the lanes t >= LPP - h.  Whatever those lanes fetch (the
     // shuffles hand them their own, finite, values) is multiplied by an exact zero.
-    template <bool FAST = false>
+    template <int FAST = 0>
     __device__ double pcr(double s, double p, double dl, double r, int &singular) const {
         s = (t_ == 0) ? 0.0 : s;
         p = (t_ == LPP - 1) ? 0.0 : p;
@@ -182,7 +191,7 @@ struct BlockGroup {
     }
     __device__ int any(int pred) const { return __syncthreads_or(pred); }
 
-    template <bool FAST = false>
+    template <int FAST = 0>
     __device__ double pcr(double s, double p, double dl, double r, int &singular) const {
         // double-buffered rows in LDS: buffer k holds s,p,dl,r at lds_[k*4*T_ + {0,1,2,3}*T_ + t]
         int cur = 0;

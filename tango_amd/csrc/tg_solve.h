@@ -19,8 +19,8 @@
 
 namespace tg {
 
-// FAST: reciprocals by recip<true> (tg_comm.h) instead of divisions.
-template <int P, bool FAST = false>
+// FAST: the division mode of the pivots' reciprocals (tg_comm.h: kDivIeee, kDivFast, kDivRounded).
+template <int P, int FAST = 0>
 struct ChunkElim {
     double e[P], f[P], l[P], rho[P];
     int singular = 0;
