@@ -5,10 +5,10 @@
 // Divisions by quantities that are constant over a launch (dx, dx^2, 2dx, dt) can be done as
 // multiplications by a reciprocal formed once (an fp64 divide costs ~15 fp64 issue slots on gfx950 and
 // the assembly has nine of them per grid point).  That changes a coefficient by at most one ulp
-// relative to the reference's true division.  The template flag EXACT selects the true divisions: the
-// standalone kernels and the large-grid (n > 512, condition number > 1e9) fused path use them, the
-// wave-per-profile fused path uses reciprocals.  All branches are written as selects so that a lane's
-// eight points form one straight-line block the scheduler can interleave.
+// relative to the reference's true division.  The template flag EXACT selects correctly rounded quotients
+// instead (quot of tg_comm.h): the standalone kernels and the large-grid (n > 512, condition number > 1e9) fused
+// path use them, the wave-per-profile fused path uses reciprocals.  All branches are written as selects so that
+// a lane's eight points form one straight-line block the scheduler can interleave.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -21,7 +21,7 @@ namespace tg {
 // operands in the normal range, at two thirds of its issue slots.)
 template <bool EXACT>
 __device__ __forceinline__ double cdiv(double x, double d, double inv) {
-    if constexpr (EXACT) return quot<true>(x, d);
+    if constexpr (EXACT) return quot<kDivRounded>(x, d);
     else return x * inv;
 }
 
