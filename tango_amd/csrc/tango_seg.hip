@@ -97,7 +97,7 @@ __global__ void seg_halo_kernel(tg_state_1f S_, SegWork W) {
 // phases 0 and 1: one wavefront per segment
 // ------------------------------------------------------------------------------------------
 template <int PHASE>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, PHASE == 0 ? 3 : 4)      // three (four) wavefronts per SIMD: <= 168 (128) registers
 picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
     extern __shared__ double lds[];
     using G = WaveGroup<64>;
@@ -134,7 +134,8 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
     const bool turb = !Q.frozen_turb;
 
     using Tile = WaveTile<8>;
-    Tile wt(lds + (threadIdx.x >> 6) * 4 * Tile::kDoubles);
+    constexpr int NT = (PHASE == 0) ? 3 : 2;      // LDS tiles per wavefront: few enough for three wavefronts per SIMD
+    Tile wt(lds + (threadIdx.x >> 6) * NT * Tile::kDoubles);
 
     double u[P + 2], um1[P], DE[P], cE[P];
     // values at the point just outside this wavefront's segment, on the side of this lane if it is lane 0 or 63
@@ -166,16 +167,16 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
         wt.stage(0, r0);
         wt.stage(1, r1);
         wt.stage(2, r2);
-        wt.stage(3, r3);
         Tile::sync();
         wt.take(0, u + 1);
         wt.take(1, ue);
         wt.take(2, DE);
-        wt.take(3, cE);
         Tile::sync();
-        wt.stage(0, r4);
+        wt.stage(0, r3);
+        wt.stage(1, r4);
         Tile::sync();
-        wt.take(0, um1);
+        wt.take(0, cE);
+        wt.take(1, um1);
         Tile::sync();
 
         auto split = [&](double pm, double p, double pp, bool first, bool last, double &D, double &c) {
@@ -212,13 +213,13 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
                 DE[i] = Q.a_turb * D + omt * (seeded ? DE[i] : D);
                 cE[i] = Q.a_turb * c + omt * (seeded ? cE[i] : c);
             }
-            wt.put(1, ue);
-            wt.put(2, DE);
-            wt.put(3, cE);
+            wt.put(0, ue);
+            wt.put(1, DE);
+            wt.put(2, cE);
             Tile::sync();
-            wt.flush(1, S_.uE + woff);
-            wt.flush(2, S_.DE + woff);
-            wt.flush(3, S_.cE + woff);
+            wt.flush(0, S_.uE + woff);
+            wt.flush(1, S_.DE + woff);
+            wt.flush(2, S_.cE + woff);
         } else {
             h_D = n_D;
             h_c = n_c;
@@ -235,11 +236,13 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
         }
         wt.stage(0, r2);
         wt.stage(1, r3);
-        wt.stage(2, r4);
         Tile::sync();
         wt.take(0, DE);
         wt.take(1, cE);
-        wt.take(2, um1);
+        Tile::sync();
+        wt.stage(0, r4);
+        Tile::sync();
+        wt.take(0, um1);
         Tile::sync();
     }
 
@@ -433,10 +436,11 @@ int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
     TG_HIP(hipMemsetAsync(W.sing, 0, sizeof(int32_t) * (size_t)nb, s));
     const int64_t segs = nb * (n / kSeg);
     const unsigned grid = (unsigned)((segs + 3) / 4);
-    const size_t lds = 4 * 4 * WaveTile<8>::kDoubles * sizeof(double);
+    const size_t tile = 4 * WaveTile<8>::kDoubles * sizeof(double);     // one tile for each of the four wavefronts
+    const size_t lds0 = 3 * tile, lds1 = 2 * tile;
     const int64_t bounds = nb * (n / kSeg - 1);
     hipLaunchKernelGGL(seg_halo_kernel, dim3((unsigned)((bounds + 255) / 256)), dim3(256), 0, s, *st, W);
-    hipLaunchKernelGGL((picard_seg_kernel<0>), dim3(grid), dim3(256), lds, s, *st, *q, W);
+    hipLaunchKernelGGL((picard_seg_kernel<0>), dim3(grid), dim3(256), lds0, s, *st, *q, W);
     const int lanes = n / 64;      // threads of the reduce kernel: 8 reduced rows each
     const size_t lds_r = sizeof(double) * 8 * (size_t)lanes;
     switch (lanes) {
@@ -445,6 +449,6 @@ int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
     case 512: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<512>>), dim3((unsigned)nb), dim3(512), lds_r, s, *st, *q, W); break;
     default: return fail(TG_ERR_UNSUPPORTED, "segmented form: n must be 8192, 16384 or 32768%s");
     }
-    hipLaunchKernelGGL((picard_seg_kernel<1>), dim3(grid), dim3(256), lds, s, *st, *q, W);
+    hipLaunchKernelGGL((picard_seg_kernel<1>), dim3(grid), dim3(256), lds1, s, *st, *q, W);
     return launch_check();
 }
