@@ -804,13 +804,38 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         bool settled = done;
         bool tread_limit = false;
         double dtau = dt_full;
+        // Upwinding weights (tango/HToMatrixFD.py:277-297).  Where diffusion dominates, H2 >= |H3| dx / 2 with
+        // H3 != 0, betaStar = 1 - H2/(c dx) <= 1/2 for c > 0 and -H2/(c dx) >= 1/2 for c < 0, so the weight is 1/2
+        // whatever the quotient (the test is exact: halving is, and the rounded quotient is monotone in its
+        // operands).  When that holds at every half point the wavefront uses, the quotients are skipped; the weights
+        // and everything computed from them are the same numbers either way.  The half point left of the first grid
+        // point carries H2 = H3 = 0 and its weight multiplies zeros; rows past the end of a ragged grid and the
+        // Dirichlet row do not use theirs.
+        bool half = true;
+        {
+            auto dominated = [&](double h2, double h3) { return (h3 != 0.0) && (h2 >= 0.5 * fabs(h3 * rc.dx)); };
+            if (!lane_first && (FULL || j0 < n - 1)) half = dominated((h2l + h2first) / 2.0, (h3l + h3first) / 2.0);
+            double a2 = h2first, a3 = h3first;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int j = j0 + i;
+                const bool used = FULL ? !(i == P - 1 && t == G::T - 1) : (j < n - 1);
+                const double n2 = (i == P - 1) ? h2r : H2at(i < P - 1 ? i + 1 : 0);
+                const double n3 = (i == P - 1) ? h3r : H3at(i < P - 1 ? i + 1 : 0);
+                half = half && (!used || dominated((a2 + n2) / 2.0, (a3 + n3) / 2.0));
+                a2 = n2;
+                a3 = n3;
+            }
+        }
+        const bool half_everywhere = __all(half);
 #pragma unroll 1
         for (int attempt = 0;; ++attempt) {
         ChunkElim<P, DIV> el;
+        double mx = 0.0, ss = 0.0;
         double hm2 = lane_first ? 0.0 : (h2l + h2first) / 2.0;
         double hm3 = lane_first ? 0.0 : (h3l + h3first) / 2.0;
-        double bm = fbeta_point<DIV>(hm2, hm3, rc.dx);
-        double mx = 0.0, ss = 0.0;
+        double bm = 0.5;
+        if (!half_everywhere) bm = fbeta_point<DIV>(hm2, hm3, rc.dx);     // a branch the whole wavefront takes or skips
         double h2c = h2first, h3c = h3first;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
@@ -822,7 +847,8 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             const double h3n = (i == P - 1) ? h3r : H3at(i < P - 1 ? i + 1 : 0);
             const double hp2 = (h2c + h2n) / 2.0;
             const double hp3 = (h3c + h3n) / 2.0;
-            const double bp = fbeta_point<DIV>(hp2, hp3, rc.dx);
+            double bp = 0.5;
+            if (!half_everywhere) bp = fbeta_point<DIV>(hp2, hp3, rc.dx);
             const double H1 = Q.H1 ? Q.H1[jc] : 1.0;
             const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + jc] : ((j < src_cut) ? S0 : 0.0);
             double A, B, C, f;
