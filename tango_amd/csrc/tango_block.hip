@@ -406,11 +406,9 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         elp.push(i, Cm, Bm, Am, d);
     }
     double tot = 0.0;
+    g.template max_and_sum<3>(mx, ss);
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const double m = g.max(mx[s]);
-        tot += g.sum(ss[s]) / (m * m);
-    }
+    for (int s = 0; s < 3; ++s) tot += ss[s] / (mx[s] * mx[s]);
     const double rms = sqrt(1.0 / (3.0 * (double)n) * tot);
 
     double xn[P];

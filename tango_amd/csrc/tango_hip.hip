@@ -872,9 +872,9 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         }
         // rms of r / max|f| (tango/fieldgroups.py:140, tango/solver.py:464-470): the first solve's matrix decides
         if (attempt == 0) {
-            mx = g.max(mx);
-            ss = g.sum(ss);
-            rms = sqrt(1.0 / (double)n * quot<DIV>(ss, mx * mx));
+            double mxv[1] = {mx}, ssv[1] = {ss};
+            g.template max_and_sum<1>(mxv, ssv);
+            rms = sqrt(1.0 / (double)n * quot<DIV>(ssv[0], mxv[0] * mxv[0]));
         }
 
         double xt[P];

@@ -94,6 +94,15 @@ struct WaveGroup {
         for (int m = LPP >> 1; m > 0; m >>= 1) pred |= __shfl_xor(pred, m, LPP);
         return pred;
     }
+    // CNT maxima and CNT sums over the group in one go (one pair of barriers for a workgroup-sized group)
+    template <int CNT>
+    __device__ void max_and_sum(double (&mx)[CNT], double (&sm)[CNT]) const {
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            mx[q] = max(mx[q]);
+            sm[q] = sum(sm[q]);
+        }
+    }
     // Parallel cyclic reduction of the unit-diagonal system s_t y_{t-1} + y_t + p_t y_{t+1} = r_t.
     // dl_t = 1 + s_t + p_t (the row's diagonal-dominance slack) is carried along and every new diagonal is
     // formed as slack - s - p: for the M-matrices of the transport problem (s, p <= 0 <= dl) all those sums
@@ -190,6 +199,39 @@ struct BlockGroup {
         return tot;
     }
     __device__ int any(int pred) const { return __syncthreads_or(pred); }
+    // CNT maxima and CNT sums over the workgroup with one pair of barriers; needs 2*CNT*(T_/64) doubles of LDS.
+    // The per-wavefront partial results are combined in wavefront order, as sum() and max() combine them.
+    template <int CNT>
+    __device__ void max_and_sum(double (&mx)[CNT], double (&sm)[CNT]) const {
+        constexpr int W = T_ / 64;
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) {
+                mx[q] = fmax(mx[q], __shfl_xor(mx[q], m, 64));
+                sm[q] += __shfl_xor(sm[q], m, 64);
+            }
+        }
+        if ((t_ & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < CNT; ++q) {
+                lds_[(2 * q) * W + (t_ >> 6)] = mx[q];
+                lds_[(2 * q + 1) * W + (t_ >> 6)] = sm[q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            double m = lds_[(2 * q) * W], tot = 0.0;
+#pragma unroll
+            for (int w = 1; w < W; ++w) m = fmax(m, lds_[(2 * q) * W + w]);
+#pragma unroll
+            for (int w = 0; w < W; ++w) tot += lds_[(2 * q + 1) * W + w];
+            mx[q] = m;
+            sm[q] = tot;
+        }
+        __syncthreads();
+    }
 
     template <int FAST = 0>
     __device__ double pcr(double s, double p, double dl, double r, int &singular) const {

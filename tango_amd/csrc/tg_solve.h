@@ -67,9 +67,19 @@ struct ChunkElim {
             }
             (void)L;
             // first-row coefficients of the lane to the right (an identity row past the end)
-            const double F0 = g.from_right(F, 1, 0.0);
-            const double E0 = g.from_right(E, 1, 0.0);
-            const double T0 = g.from_right(tau, 1, 1.0);
+            double F0, E0, T0;
+            if constexpr (G::kBlock) {      // one exchange (one pair of barriers) instead of three
+                const double v[3] = {F, E, tau};
+                double lq[3], rq[3];
+                g.template exchange<3>(v, 1, lq, rq);
+                F0 = rq[0];
+                E0 = rq[1];
+                T0 = (g.t() + 1 < G::T) ? rq[2] : 1.0;
+            } else {
+                F0 = g.from_right(F, 1, 0.0);
+                E0 = g.from_right(E, 1, 0.0);
+                T0 = g.from_right(tau, 1, 1.0);
+            }
             // reduced row in y: ll y_{t-1} + (1 - el L0) y_t - el E0 y_{t+1} = fl - el F0, slack = rl - el T0
             const double el = e[P - 1], ll = l[P - 1], fl = f[P - 1], rl = rho[P - 1];
             const double sig = rl - el * T0;
