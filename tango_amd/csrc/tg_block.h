@@ -206,18 +206,20 @@ struct RowPack {
 // dl_t = (S_t + I + P_t) 1 is the slack vector of the row, carried as in the scalar reduction.
 template <int K, int FAST = 0, class G>
 __device__ __forceinline__ Vec<K> block_pcr(const G &g, Mat<K> S, Mat<K> Pm, Vec<K> dl, Vec<K> r, int &singular) {
+    // No special cases at the ends: the first lane has no left coupling (S = 0, enforced here) and by induction S = 0
+    // in every lane t < h at the level of distance h (S2 = -S Sm with Sm from a lane below h), likewise Pm = 0 in the
+    // lanes t >= T - h; whatever finite rows those lanes receive instead of a neighbour's is multiplied by exact zeros.
+    if (g.t() == 0) S = mat_zero<K>();
+    if (g.t() == G::T - 1) Pm = mat_zero<K>();
 #pragma unroll 1
     for (int h = 1; h < G::T; h <<= 1) {
         RowPack<K> me, lf, rt;
         me.set(S, Pm, dl, r);
-        g.template exchange<RowPack<K>::N>(me.q, h, lf.q, rt.q);   // rows of lanes t-h and t+h, zeros past the ends
+        g.template exchange_nofill<RowPack<K>::N>(me.q, h, lf.q, rt.q);   // rows of lanes t-h and t+h
         Mat<K> Sm, Pmm, Sp, Pp;
         Vec<K> dm, dp, rm, rp;
         lf.get(Sm, Pmm, dm, rm);
         rt.get(Sp, Pp, dp, rp);
-        const int t = g.t();
-        if (t < h) dm = rowsum(mat_identity<K>(1.0));          // identity rows beyond the ends: slack 1
-        if (t + h >= G::T) dp = rowsum(mat_identity<K>(1.0));
         // (-S Sm) y_{t-2h} + (I - S Pmm - Pm Sp) y_t + (-Pm Pp) y_{t+2h} = r - S rm - Pm rp
         const Mat<K> S2 = neg(mul(S, Sm));
         const Mat<K> P2 = neg(mul(Pm, Pp));

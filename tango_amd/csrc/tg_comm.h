@@ -79,6 +79,16 @@ struct WaveGroup {
             r[q] = from_right(v[q], h, 0.0);
         }
     }
+    // the same without fill values: a lane without such a neighbour receives its own values (for callers that
+    // multiply them by an exact zero, like the cyclic reductions)
+    template <int CNT>
+    __device__ void exchange_nofill(const double (&v)[CNT], int h, double (&l)[CNT], double (&r)[CNT]) const {
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            l[q] = __shfl_up(v[q], (unsigned)h, LPP);
+            r[q] = __shfl_down(v[q], (unsigned)h, LPP);
+        }
+    }
     __device__ double sum(double v) const {
 #pragma unroll
         for (int m = LPP >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, LPP);
@@ -176,6 +186,21 @@ struct BlockGroup {
         }
         __syncthreads();
     }
+    // the same without fill values: a thread without such a neighbour receives the values of the thread T_ places
+    // further on or back (for callers that multiply them by an exact zero, like the cyclic reductions)
+    template <int CNT>
+    __device__ void exchange_nofill(const double (&v)[CNT], int h, double (&l)[CNT], double (&r)[CNT]) const {
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) lds_[q * T_ + t_] = v[q];
+        __syncthreads();
+        const int tl = (t_ - h) & (T_ - 1), tr = (t_ + h) & (T_ - 1);
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            l[q] = lds_[q * T_ + tl];
+            r[q] = lds_[q * T_ + tr];
+        }
+        __syncthreads();
+    }
     __device__ double sum(double v) const {
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -236,6 +261,10 @@ struct BlockGroup {
     template <int FAST = 0>
     __device__ double pcr(double s, double p, double dl, double r, int &singular) const {
         // double-buffered rows in LDS: buffer k holds s,p,dl,r at lds_[k*4*T_ + {0,1,2,3}*T_ + t]
+        // no special cases at the ends: a thread without a neighbour at distance h has an exactly zero coupling on
+        // that side (see WaveGroup::pcr) and reads the row T_ places away instead, whose values it multiplies by zero
+        s = (t_ == 0) ? 0.0 : s;
+        p = (t_ == T_ - 1) ? 0.0 : p;
         int cur = 0;
 #pragma unroll 1
         for (int h = 1; h < T_; h <<= 1) {
@@ -245,9 +274,9 @@ struct BlockGroup {
             bd[t_] = dl;
             br[t_] = r;
             __syncthreads();
-            double sm = 0.0, dm = 1.0, rm = 0.0, pp = 0.0, dp = 1.0, rp = 0.0;
-            if (t_ >= h) { sm = bs[t_ - h]; dm = bd[t_ - h]; rm = br[t_ - h]; }
-            if (t_ + h < T_) { pp = bp[t_ + h]; dp = bd[t_ + h]; rp = br[t_ + h]; }
+            const int tl = (t_ - h) & (T_ - 1), tr = (t_ + h) & (T_ - 1);
+            const double sm = bs[tl], dm = bd[tl], rm = br[tl];
+            const double pp = bp[tr], dp = bd[tr], rp = br[tr];
             const double d2 = dl - s * dm - p * dp;
             const double s2 = -(sm * s);
             const double p2 = -(pp * p);
