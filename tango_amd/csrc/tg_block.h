@@ -211,7 +211,7 @@ __device__ __forceinline__ Vec<K> block_pcr(const G &g, Mat<K> S, Mat<K> Pm, Vec
     // lanes t >= T - h; whatever finite rows those lanes receive instead of a neighbour's is multiplied by exact zeros.
     if (g.t() == 0) S = mat_zero<K>();
     if (g.t() == G::T - 1) Pm = mat_zero<K>();
-#pragma unroll 1
+#pragma unroll
     for (int h = 1; h < G::T; h <<= 1) {
         RowPack<K> me, lf, rt;
         me.set(S, Pm, dl, r);

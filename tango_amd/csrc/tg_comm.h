@@ -266,7 +266,7 @@ struct BlockGroup {
         s = (t_ == 0) ? 0.0 : s;
         p = (t_ == T_ - 1) ? 0.0 : p;
         int cur = 0;
-#pragma unroll 1
+#pragma unroll
         for (int h = 1; h < T_; h <<= 1) {
             double *bs = lds_ + cur * 4 * T_, *bp = bs + T_, *bd = bp + T_, *br = bd + T_;
             bs[t_] = s;
