@@ -244,7 +244,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const int j = j0 + i;
-            const bool first = (j == 0), last = (j == n - 1);
+            const bool first = FULL ? (i == 0 && lane_first) : (j == 0);
+            const bool last = FULL ? (i == P - 1 && t == G::T - 1) : (j == n - 1);
             double dd[3];
 #pragma unroll
             for (int s = 0; s < 3; ++s) dd[s] = ddx_edge1_point<EXACT>(ue[s][i], ue[s][i + 1], ue[s][i + 2], first, last, rc);
@@ -353,8 +354,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int j = j0 + i;
-        const bool valid = j < n;
-        const bool last = (j == n - 1);
+        const bool valid = FULL || j < n;      // FULL: n = lanes x P, the tests fold away
+        const bool last = FULL ? (i == P - 1 && t == G::T - 1) : (j == n - 1);
         const int jc = valid ? j : n - 1;
         // collisional coupling nu = nu0 / ((pi + pe)/n)^{3/2} from the current profiles (example :108-110)
         const double q = quot<DIV>(u[1][i + 1], u[0][i + 1]) + quot<DIV>(u[2][i + 1], u[0][i + 1]);
@@ -380,7 +381,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             h3c[s] = h3n;
         }
         const double Gc = (valid && !last) ? -nu : 0.0;   // G = -H8 = -nu, zero on the Dirichlet row (JK_to_matrix_fd.py:126-129)
-        const double up[3] = {(j < n - 1) ? u[0][i + 2] : 0.0, (j < n - 1) ? u[1][i + 2] : 0.0, (j < n - 1) ? u[2][i + 2] : 0.0};
+        const bool inner = FULL ? !last : (j < n - 1);
+        const double up[3] = {inner ? u[0][i + 2] : 0.0, inner ? u[1][i + 2] : 0.0, inner ? u[2][i + 2] : 0.0};
         double r[3];
         r[0] = A[0] * up[0] + B[0] * u[0][i + 1] + C[0] * u[0][i] - f[0];
         r[1] = A[1] * up[1] + B[1] * u[1][i + 1] + C[1] * u[1][i] + Gc * u[2][i + 1] - f[1];
@@ -421,7 +423,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     for (int i = 0; i < P; ++i) {
         xi[i] = xp[i].v[0];
         xe[i] = xp[i].v[1];
-        if (j0 + i < n) bad |= !(isfinite(xn[i]) && xn[i] >= 0.0 && isfinite(xi[i]) && xi[i] >= 0.0 && isfinite(xe[i]) && xe[i] >= 0.0);
+        if (FULL || j0 + i < n) bad |= !(isfinite(xn[i]) && xn[i] >= 0.0 && isfinite(xi[i]) && xi[i] >= 0.0 && isfinite(xe[i]) && xe[i] >= 0.0);
     }
     if constexpr (COOP) {
         wt.put(0, xn); wt.put(1, xi); wt.put(2, xe);
