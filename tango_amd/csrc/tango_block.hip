@@ -210,6 +210,16 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             load_chunk<P, false>(S_.cE[s] + off, n, j0, cE[s], 0.0);
         }
     }
+    // a y + (1 - a) memory, the first iterate seeding the memory (tango/lodestro_method.py:706-708).  `seeded` is the
+    // same for the whole wavefront unless several profiles share it: a branch then, not a select.
+    auto ewma = [&](double a, double y, double om, double mem) -> double {
+        if constexpr (G::kBlock || G::T == 64) {
+            if (seeded) return a * y + om * mem;
+            return a * y + om * y;
+        } else {
+            return a * y + om * (seeded ? mem : y);
+        }
+    };
     if (turb) {
         double ue[3][P + 2];
 #pragma unroll
@@ -217,7 +227,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             if constexpr (COOP) wt.take(1 + s, ue[s] + 1);
             else load_chunk<P, false>(S_.uE[s] + off, n, j0, ue[s] + 1, 1.0);
 #pragma unroll
-            for (int i = 0; i < P; ++i) ue[s][i + 1] = Q.a_prof * u[s][i + 1] + omp * (seeded ? ue[s][i + 1] : u[s][i + 1]);
+            for (int i = 0; i < P; ++i) ue[s][i + 1] = ewma(Q.a_prof, u[s][i + 1], omp, ue[s][i + 1]);
             if constexpr (!COOP) store_chunk<P, false>(S_.uE[s] + off, n, j0, ue[s] + 1);
         }
         if constexpr (COOP) {
@@ -257,8 +267,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
                     const double flux = -Dsh * dd[s];
                     double D, c, DH, cH, thv;
                     flux_split_point<DIV>(flux, ue[s][i + 1], dd[s], 1.0, 1.0, th, D, c, DH, cH, thv);
-                    DE[s][i] = Q.a_turb * D + omt * (seeded ? DE[s][i] : D);
-                    cE[s][i] = Q.a_turb * c + omt * (seeded ? cE[s][i] : c);
+                    DE[s][i] = ewma(Q.a_turb, D, omt, DE[s][i]);
+                    cE[s][i] = ewma(Q.a_turb, c, omt, cE[s][i]);
                 }
             } else {
                 // the same through the quotient r = (dpi/dx)/pi: DHat = -flux/(du/dx) = r^2 for every field (0 where
@@ -271,8 +281,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
                     const double cHat = (s == 1) ? -(Dsh * r) : quot<true>(-(Dsh * dd[s]), ue[s][i + 1]);
                     double D, c;
                     split_from_hats<true>(dh, cHat, dd[s], th, D, c);
-                    DE[s][i] = Q.a_turb * D + omt * (seeded ? DE[s][i] : D);
-                    cE[s][i] = Q.a_turb * c + omt * (seeded ? cE[s][i] : c);
+                    DE[s][i] = ewma(Q.a_turb, D, omt, DE[s][i]);
+                    cE[s][i] = ewma(Q.a_turb, c, omt, cE[s][i]);
                 }
             }
         }
