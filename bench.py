@@ -5,7 +5,7 @@
 
 One "step" = one Picard iteration (EWMA -> flux -> split -> EWMA -> assembly -> residual -> tridiagonal
 solve -> validity check) of every profile of the ensemble, all profiles forced active.  --iters-per-launch k
-(default 16) runs k consecutive steps in one kernel launch with every profile held in registers in between: the
+(default 64) runs k consecutive steps in one kernel launch with every profile held in registers in between: the
 arithmetic, the per-iteration convergence test and the residual history are those of k single launches, only
 the HBM round trip of the state between iterations is gone (k = 1 gives the one-launch-per-iteration form).  Each GPU (one
 process per GPU; for N > 1 launch through torch.distributed.run) holds 65 536 profiles x 512 grid points,
@@ -82,10 +82,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=192)
-    ap.add_argument('--warmup', type=int, default=16)
-    ap.add_argument('--iters-per-launch', type=int, default=16,
+    ap.add_argument('--warmup', type=int, default=64)
+    ap.add_argument('--iters-per-launch', type=int, default=64,
                     help='Picard iterations per kernel launch (profiles stay in registers in between); 1 = one launch per step')
-    ap.add_argument('--check-every', type=int, default=16, help='steps between convergence-counter all-reduces')
+    ap.add_argument('--check-every', type=int, default=64, help='steps between convergence-counter all-reduces')
     ap.add_argument('--profiles-per-gpu', type=int, default=PROFILES_PER_GPU)
     ap.add_argument('--n', type=int, default=N_GRID)
     ap.add_argument('--no-cpu-baseline', action='store_true')

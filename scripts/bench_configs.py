@@ -119,7 +119,7 @@ def single_profile(n=500):
                           'converged': bool(s.converged)}), flush=True)
 
 
-def convergence(nb=65536, n=512, k=16):
+def convergence(nb=65536, n=512, k=64):
     st = torch.cuda.current_stream().cuda_stream
     E = OneFieldEnsemble(shestakov_ensemble(nb, n), a_turb=0.3, a_prof=1.0, tol=1e-11, fixed_count=False, keep_err=False)
     torch.cuda.synchronize()

@@ -6,7 +6,8 @@ k=$1; steps=${2:-96}
 out=$PWD/gpurun_out/prof_bench_k$k
 mkdir -p $out
 export TMPDIR=/tmp
-args="bench.py --steps $steps --warmup 16 --iters-per-launch $k --no-cpu-baseline"
+warm=$(( k > 16 ? k : 16 ))     # warm-up launches of the same shape as the timed ones
+args="bench.py --steps $steps --warmup $warm --iters-per-launch $k --check-every $k --no-cpu-baseline"
 timeout -s KILL 170 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $args > $out/trace.log 2>&1
 timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $args > $out/fetch.log 2>&1
 timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $args > $out/write.log 2>&1
