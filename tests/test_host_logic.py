@@ -189,3 +189,33 @@ def test_flux_decorators_match_reference():
     np.random.seed(5)
     nz = noisyflux.NoisyFlux(M(), 0.1, 0.05, 1 / 199).get_flux({})['n']
     assert nz.shape == (3, 200) and not np.allclose(nz[0], nz[1]) and np.array_equal(nz[:, 0], v[[0, 0, 0]])
+
+
+def test_static_callback_detection():
+    """Solver's trial calls: a callback whose own coefficients depend on x only is recognised; dependence on the
+    profile, on time, or an exception is not; a static_H attribute overrides the trial."""
+    from types import SimpleNamespace
+    from tango_amd.solver import _callback_is_static
+    x = np.linspace(0, 1, 12)
+    H = multifield.HCoefficients
+
+    def mk(cb, detect=True):
+        f = SimpleNamespace(label='n', compute_all_H=cb)
+        return SimpleNamespace(fields=[f], profiles={'n': 1 - 0.5 * x}, x=x, tArray=np.array([0.0, 2.0]), detectStaticH=detect)
+
+    static = lambda t, xx, p, HT: H(H1=np.ones_like(xx), H7=np.where(xx < 0.3, 2.0, 0.0)) + HT
+    assert _callback_is_static(mk(static))
+    assert not _callback_is_static(mk(static, detect=False))
+    assert not _callback_is_static(mk(lambda t, xx, p, HT: H(H1=np.ones_like(xx), H7=p['n']) + HT))
+    assert not _callback_is_static(mk(lambda t, xx, p, HT: H(H1=np.ones_like(xx) * (1 + t)) + HT))
+    assert not _callback_is_static(mk(lambda t, xx, p, HT: 1 / 0))
+    assert not _callback_is_static(mk(lambda t, xx, p, HT: None))
+
+    class Marked(object):
+        static_H = False
+
+        def __call__(self, t, xx, p, HT):
+            return H(H1=np.ones_like(xx)) + HT
+    assert not _callback_is_static(mk(Marked()))
+    Marked.static_H = True
+    assert _callback_is_static(mk(Marked(), detect=False))
