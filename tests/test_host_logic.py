@@ -219,3 +219,23 @@ def test_static_callback_detection():
     assert not _callback_is_static(mk(Marked()))
     Marked.static_H = True
     assert _callback_is_static(mk(Marked(), detect=False))
+
+
+def test_ewma_memory_handed_over_as_a_callable_is_fetched_once():
+    """The fused solver paths leave an ensemble's EWMA memories on the device and hand lodestro_method.EWMA a
+    callable; the first read calls it, later reads use the value; plain arrays and None behave as in the reference."""
+    from tango_amd.lodestro_method import EWMA
+    calls = []
+
+    def fetch():
+        calls.append(1)
+        return np.array([1.0, 2.0])
+    e = EWMA(0.3)
+    assert e._yEWMA_lminus1 is None
+    e.set_ewma_iterate(fetch)
+    assert not calls
+    assert np.array_equal(e._yEWMA_lminus1, [1.0, 2.0]) and np.array_equal(e._yEWMA_lminus1, [1.0, 2.0]) and len(calls) == 1
+    e.set_ewma_iterate(np.array([5.0]))
+    assert np.array_equal(e._yEWMA_lminus1, [5.0]) and len(calls) == 1
+    e.reset_ewma_iterate()
+    assert e._yEWMA_lminus1 is None
