@@ -88,7 +88,7 @@ def test_block3_solve(tango, n):
     assert relerr(x1[:, 0], u0) < 1e-12 and relerr(x1[:, 1], u1) < 1e-12 and relerr(x1[:, 2], u2) < 1e-12
 
 
-def make_3f_solver(tango, N, nu0, BCs, tol=1e-9, maxit=1000, inner=0, fused=True, ic=None, **kw):
+def make_3f_solver(tango, N, nu0, BCs, tol=1e-9, maxit=1000, inner=0, fused=True, ic=None, ewma=(0.3, 0.3), dt=1e6, **kw):
     T = tango.extras.threefield
     dx = 1 / (N - 1); x = np.arange(N) * dx
     th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
@@ -96,14 +96,14 @@ def make_3f_solver(tango, N, nu0, BCs, tol=1e-9, maxit=1000, inner=0, fused=True
     cbs = [T.ComputeAllH_n(), T.ComputeAllH_pi(nu0), T.ComputeAllH_pe(nu0)]
     if not fused:     # plain callables -> generic path
         cbs = [(lambda cb: (lambda t, xx, p, HT: cb(t, xx, p, HT)))(cb) for cb in cbs]
-    lms = [tango.lodestro_method.lm(0.3, 0.3, th) for _ in range(3)]
+    lms = [tango.lodestro_method.lm(ewma[0], ewma[1], th) for _ in range(3)]
     F = tango.multifield.Field
     fields = [F(label='n', rightBC=BCs[0], profile_mminus1=1.0 * ic, compute_all_H=cbs[0], lodestroMethod=lms[0]),
               F(label='pi', rightBC=BCs[1], profile_mminus1=1.0 * ic, compute_all_H=cbs[1], lodestroMethod=lms[1], coupledTo='pe'),
               F(label='pe', rightBC=BCs[2], profile_mminus1=1.0 * ic, compute_all_H=cbs[2], lodestroMethod=lms[2], coupledTo='pi')]
     tango.multifield.check_fields_initialize(fields)
     call = tango.multifield.ComputeAllHAllFields(fields, tango.lodestro_method.TurbulenceHandler(dx, x, T.ShestakovThreeFieldFluxModel(dx)))
-    return tango.solver.Solver(1, x, np.array([0, 1e6]), maxit, tol, call, fields, useInnerIteration=inner > 0,
+    return tango.solver.Solver(1, x, np.array([0, dt]), maxit, tol, call, fields, useInnerIteration=inner > 0,
                                innerIterationMaxCount=max(inner, 1), **kw), lms
 
 
@@ -171,3 +171,30 @@ def test_threefield_ensemble(tango, golden):
                                           0.3, 0.3, 1e-9, 1000)
         assert abs(int(s.iterationsPerProfile[b]) - it) <= 1
         assert relerr(s.profiles['n'][b], n) < TOL and relerr(s.profiles['pi'][b], pi) < TOL and relerr(s.profiles['pe'][b], pe) < TOL
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_threefield_random_problems_vs_oracle(tango, seed):
+    """Randomly drawn grids, collision frequencies, boundary values, EWMA parameters and timesteps, a fixed number of
+    iterations: the fused three-field kernel (one wavefront or one workgroup per profile, full and ragged grids)
+    against the CPU oracle, member by member."""
+    rng = np.random.default_rng(500 + seed)
+    N = int(rng.choice([64, 100, 255, 256, 500, 512, 1024]))
+    nb = int(rng.integers(1, 5))
+    its = int(rng.integers(3, 10))
+    a_turb, a_prof = float(rng.uniform(0.1, 0.5)), float(rng.choice([1.0, rng.uniform(0.1, 1.0)]))
+    dt = float(10 ** rng.uniform(2, 6))
+    ens = orc.threefield_ensemble(nb + 1, N, seed=seed)
+    nu0, bc, ic = ens['nu0'][1:].copy(), ens['bc'][1:].copy(), ens['u0'][1:].copy()
+    s, _ = make_3f_solver(tango, N, nu0, (bc[:, 0].copy(), bc[:, 1].copy(), bc[:, 2].copy()), ic=ic, tol=1e-30, maxit=its,
+                          ewma=(a_turb, a_prof), dt=dt, iterationsPerCheck=int(rng.integers(1, 4)))
+    assert s._fused is not None and s.batched
+    s.take_timestep()
+    assert not s.solutionError and np.all(s.iterationsPerProfile == its)
+    bar = TOL if N <= 512 else 3e-10
+    for b in range(nb):
+        (n, pi, pe), it, err = orc.run_3f(ic[b], ic[b], ic[b], dt, ens['dx'], tuple(bc[b]), nu0[b], ens['x'], a_turb, a_prof, 1e-30, its,
+                                          fixed_count=True)
+        for lab, ref in (('n', n), ('pi', pi), ('pe', pe)):
+            assert relerr(s.profiles[lab][b], ref) < bar, (seed, b, lab, N, dt)
+        assert np.allclose(s.errHistory[b, :its], err[:its], rtol=1e-6, atol=1e-11), (seed, b)
