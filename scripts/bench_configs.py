@@ -119,6 +119,35 @@ def single_profile(n=500):
                           'converged': bool(s.converged)}), flush=True)
 
 
+def single_profile_three_field(n=500):
+    """examples/shestakov_threefield_nonlinearnu.py as one profile through the Solver API (tol 1e-9): wall time."""
+    T = tango.extras.threefield
+    dx = 1.0 / (n - 1)
+    x = np.arange(n) * dx
+    th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
+    walls = []
+    for rep in range(3):
+        lms = [tango.lodestro_method.lm(0.3, 0.3, th) for _ in range(3)]
+        F = tango.multifield.Field
+        ic = 1 - 0.5 * x
+        fields = [F(label='n', rightBC=2.0, profile_mminus1=1.0 * ic, compute_all_H=T.ComputeAllH_n(), lodestroMethod=lms[0]),
+                  F(label='pi', rightBC=0.1, profile_mminus1=1.0 * ic, compute_all_H=T.ComputeAllH_pi(2.2), lodestroMethod=lms[1], coupledTo='pe'),
+                  F(label='pe', rightBC=0.3, profile_mminus1=1.0 * ic, compute_all_H=T.ComputeAllH_pe(2.2), lodestroMethod=lms[2], coupledTo='pi')]
+        tango.multifield.check_fields_initialize(fields)
+        call = tango.multifield.ComputeAllHAllFields(fields, tango.lodestro_method.TurbulenceHandler(dx, x, T.ShestakovThreeFieldFluxModel(dx)))
+        s = tango.solver.Solver(1, x, np.array([0, 1e6]), 400, 1e-9, call, fields)
+        assert s._fused is not None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.take_timestep()
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+    its = len(s.errHistoryFinal)
+    print(json.dumps({'config': 'three-field example, single profile through Solver (tol 1e-9)', 'profiles': 1, 'N': n, 'iterations': its,
+                      'wall_ms': round(min(walls) * 1e3, 3), 'us_per_iteration': round(min(walls) * 1e6 / its, 1), 'converged': bool(s.converged)}),
+          flush=True)
+
+
 def convergence(nb=65536, n=512, k=64):
     st = torch.cuda.current_stream().cuda_stream
     E = OneFieldEnsemble(shestakov_ensemble(nb, n), a_turb=0.3, a_prof=1.0, tol=1e-11, fixed_count=False, keep_err=False)
@@ -146,6 +175,7 @@ if __name__ == '__main__':
     H.set_stream(torch.cuda.current_stream().cuda_stream)
     if 'c1' in what:
         single_profile()
+        single_profile_three_field()
     if 'c2' in what:
         one_field('c2 one-field', 65536, 256, 1.0, (1, 8))
     if 'metric' in what:
