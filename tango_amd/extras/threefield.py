@@ -157,7 +157,13 @@ class Fused3F(object):
             H.check(H.lib.tg_memset(self.err.ptr, 0, self.err.nbytes, H.stream()))
         inner = s.innerIterationMaxCount if s.useInnerIteration else 0
         hist = s.profilesAllIterations
-        done = s.iterationNumber
+        done = start = s.iterationNumber
+        # The iterate history, when kept, is collected on the device (one copy per field and iteration, no host round
+        # trip) and read back once at the end; beyond 256 MiB it is streamed to the host iterate by iterate instead.
+        rows = s.maxIterations - done
+        snaps = None
+        if hist is not None and rows > 0 and 3 * rows * self.u[0].nbytes <= (256 << 20):
+            snaps = [H.DeviceArray((rows, self.nb, self.n)) for _ in self.u]
         while done < s.maxIterations:
             q.frozen_turb, q.outer_count = 0, 0
             H.check(H.lib.tg_picard_3f_step(C.byref(self.state), C.byref(q), H.stream()))
@@ -165,14 +171,25 @@ class Fused3F(object):
             q.frozen_turb, q.outer_count = 1, done
             for _ in range(inner):      # inner iteration with frozen turbulent coefficients (tango/solver.py:274-309)
                 H.check(H.lib.tg_picard_3f_step(C.byref(self.state), C.byref(q), H.stream()))
-            if hist is not None:
+            if snaps is not None:       # a profile that has stopped keeps its values: its later rows repeat them
+                for dst, d in zip(snaps, self.u):
+                    H.check(H.lib.tg_copy_d2d(dst.ptr + (done - 1 - start) * d.nbytes, d.ptr, d.nbytes, H.stream()))
+            elif hist is not None:
                 for f, d in zip(self.fields, self.u):
                     snap = d.to_host()
-                    hist[f.label][done - 1] = snap if s.batched else snap[0]
-            if done % s.iterationsPerCheck == 0 or hist is not None or done == s.maxIterations:
+                    hist[f.label][done - 1 - start] = snap if s.batched else snap[0]
+            if (done - start) % s.iterationsPerCheck == 0 or done == s.maxIterations:
                 H.check(H.lib.tg_status_reduce(self.status.ptr, self.nb, self.counts.ptr, H.stream()))
                 if int(self.counts.to_host()[0]) == 0:
                     break
+        if snaps is not None:
+            top = done - start
+            for f, dst in zip(self.fields, snaps):
+                got = np.empty((top, self.nb, self.n))
+                if top:
+                    H.check(H.lib.tg_copy_d2h(got.ctypes.data, dst.ptr, got.nbytes, H.stream()))
+                    H.check(H.lib.tg_stream_sync(H.stream()))
+                hist[f.label][:top] = got if s.batched else got[:, 0]
         self.finish(s)
 
     def finish(self, s):
