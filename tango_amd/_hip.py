@@ -198,6 +198,11 @@ class DeviceArray:
         return self.ptr
 
     @property
+    def __cuda_array_interface__(self):
+        """Lets torch.as_tensor(array, device='cuda') (and CuPy-style consumers) view the memory without a copy."""
+        return {'shape': self.shape, 'typestr': self.dtype.str, 'data': (int(self.ptr or 0), False), 'version': 2, 'strides': None}
+
+    @property
     def size(self):
         return int(np.prod(self.shape, dtype=np.int64))
 

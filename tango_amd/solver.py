@@ -584,6 +584,11 @@ class _Fused1F(object):
             m.set_ewma_iterates(self.uE.to_host()[0], self.DE.to_host()[0], self.cE.to_host()[0])
 
 
+def _torch_view(array, device):
+    import torch
+    return torch.as_tensor(array, device=device)
+
+
 class _FusedExternal1F(_Fused1F):
     """One field whose turbulent flux comes from a Python flux model (the place of a turbulence code): per
     iteration the profile EWMA is advanced and handed to fluxModel.get_flux on the host, the (optionally smoothed)
@@ -672,6 +677,8 @@ class _FusedExternal1F(_Fused1F):
             H.check(H.lib.tg_memset(self.err.ptr, 0, self.err.nbytes, H.stream()))
         done = self.start = s.iterationNumber
         hist = s.profilesAllIterations
+        if getattr(th.fluxModel, 'device_flux', False) and not th.doSmoothing:
+            return self._run_timestep_device_flux(s, q, th, a_prof)
         pick = (lambda a: a) if s.batched else (lambda a: a[0])
         u = self.u.to_host()
         while done < s.maxIterations:
@@ -680,8 +687,8 @@ class _FusedExternal1F(_Fused1F):
             if not active.any():
                 break
             # host side of the protocol: EWMA of the profiles that still iterate, flux model, smoothing
-            if self.uE_host is None:
-                self.uE_host = u.copy()
+            if self.uE_host is None:        # first iterate, or memory left on the device by a device flux model
+                self.uE_host = self.uE.to_host() if getattr(self, '_uE_on_device', False) else u.copy()
             new = a_prof * u + (1 - a_prof) * self.uE_host
             self.uE_host[active] = new[active]
             flux = np.asarray(th.fluxModel.get_flux({self.label: pick(self.uE_host)})[self.label], dtype=np.float64)
@@ -697,3 +704,54 @@ class _FusedExternal1F(_Fused1F):
                 if s.fluxesAllIterations is not None:
                     s.fluxesAllIterations[self.label][done - 1 - self.start] = flux
         self.finish(s)
+
+    def _run_timestep_device_flux(self, s, q, th, a_prof):
+        """The same loop for a flux model that lives on the GPU (attribute device_flux = True, e.g. a surrogate model
+        in PyTorch): get_flux receives the EWMA of the profiles as a CUDA torch tensor viewing this solver's memory
+        ((profiles, N), or (N,) for a single profile) and returns the flux as a CUDA tensor; nothing crosses PCIe
+        inside the iteration.  The kernel is launched on torch's current stream for the duration of the timestep."""
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError('a flux model with device_flux = True needs torch to see the GPU: import torch before tango_amd, '
+                               'so that the library shares the HIP runtime torch ships with')
+        dev = torch.device('cuda', torch.cuda.current_device())
+        u_t, uE_t, fl_t, st_t = (_torch_view(a, dev) for a in (self.u, self.uE, self.flux, self.status))
+        hist = s.profilesAllIterations
+        rows = s.maxIterations - self.start
+        snaps = None
+        if hist is not None and rows > 0 and rows * self.u.nbytes <= (256 << 20):
+            snaps = H.DeviceArray((rows, self.nb, self.n))
+        previous = H.stream()
+        H.set_stream(torch.cuda.current_stream().cuda_stream)
+        try:
+            seeded = self.uE_host is not None or getattr(self, '_uE_on_device', False)
+            done = self.start
+            while done < s.maxIterations:
+                active = (st_t & (H.ST_CONVERGED | H.ST_INVALID)) == 0
+                if (done - self.start) % s.iterationsPerCheck == 0 and not bool(active.any()):
+                    break
+                # EWMA of the profiles that still iterate (tango/lodestro_method.py:345), the first one seeding the memory
+                if not seeded:
+                    uE_t.copy_(u_t)
+                    seeded = self._uE_on_device = True
+                new = a_prof * u_t + (1 - a_prof) * uE_t
+                uE_t.copy_(torch.where(active[:, None], new, uE_t))
+                flux = th.fluxModel.get_flux({self.label: uE_t if s.batched else uE_t[0]})[self.label]
+                fl_t.copy_(torch.as_tensor(flux, device=dev).reshape(self.nb, self.n))
+                H.check(H.lib.tg_picard_1f_step(C.byref(self.state), C.byref(q), H.stream()))
+                done += 1
+                if snaps is not None:
+                    H.check(H.lib.tg_copy_d2d(snaps.ptr + (done - 1 - self.start) * self.u.nbytes, self.u.ptr, self.u.nbytes, H.stream()))
+                elif hist is not None:
+                    snap = self.u.to_host()
+                    hist[self.label][done - 1 - self.start] = snap if s.batched else snap[0]
+            if snaps is not None:
+                top = done - self.start
+                got = np.empty((top, self.nb, self.n))
+                if top:
+                    H.check(H.lib.tg_copy_d2h(got.ctypes.data, snaps.ptr, got.nbytes, H.stream()))
+                    H.check(H.lib.tg_stream_sync(H.stream()))
+                hist[self.label][:top] = got if s.batched else got[:, 0]
+            self.finish(s)
+        finally:
+            H.set_stream(previous)

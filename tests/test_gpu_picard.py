@@ -1,5 +1,6 @@
 """The fused device-resident Picard step and the Solver on top of it, against reference trajectories (golden
 vectors), the CPU oracle, and size-independent properties at the benchmark's full size."""
+import os
 import ctypes as C
 
 import numpy as np
@@ -691,3 +692,14 @@ def test_segmented_long_profiles_match_the_workgroup_kernel(tango, N, nb):
             assert relerr(y.to_host(), x.to_host()) < bar
         k = int(ia.min())
         assert np.allclose(A.err.to_host()[:, :k], B.err.to_host()[:, :k], rtol=1e-5, atol=1e-11)
+
+
+def test_flux_model_on_the_device():
+    """A flux model that lives on the GPU (tests/device_flux_case.py).  In a process of its own: torch brings its own
+    HIP runtime, which has to be loaded before libtango_hip.so for the two to share it, and this test session has
+    loaded the library long before."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, 'device_flux_case.py')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'device flux case ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
