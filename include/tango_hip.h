@@ -70,9 +70,12 @@ int tg_stream_probe(const double *const in[5], double *const out[4], int64_t cou
  * C_j u_{j-1} + B_j u_j + A_j u_{j+1} = D_j, j = 0..n-1; A[n-1] and C[0] are ignored (LAPACK's band
  * storage never reads them).  u may alias D.
  *  - point-fastest: one wavefront (or one workgroup when n > 512) per profile, chunked elimination +
- *    parallel cyclic reduction across lanes; no work space needed (work may be NULL);
- *  - batch-fastest: one lane per profile, Thomas sweeps; needs tg_tridiag_work_bytes() of work space
- *    for the forward-sweep multipliers.
+ *    parallel cyclic reduction across lanes; no work space needed (work may be NULL); n <= 16384; no pivoting
+ *    (within rounding of dgtsv for the diagonally dominant matrices of the transport problem);
+ *  - batch-fastest: one lane per profile performing LAPACK dgtsv's sweeps operation by operation, row
+ *    interchanges included, without floating-point contraction: bit-identical to the reference's result.  Needs
+ *    tg_tridiag_work_bytes() of work space (pivots, modified super-diagonal, second super-diagonal).  u may
+ *    alias D but not A, B or C.
  * status: optional (nb,) int32, TG_ST_SINGULAR is OR-ed in for a profile that met a zero pivot. */
 size_t tg_tridiag_work_bytes(int64_t nb, int64_t n, int layout);
 int tg_tridiag_solve(const double *A, const double *B, const double *C, const double *D, double *u,
@@ -148,7 +151,9 @@ int tg_block3_solve(const double *Cb, const double *Bb, const double *Ab, const 
  * One call = one pass (or, with iters_per_launch = k, up to k passes) of tango/solver.py:188-272 (compute_next_iteration) for every active profile of
  * the ensemble with the analytic flux built in: EWMA(profile) -> flux -> [smoothing] -> FluxSplit ->
  * EWMA(D), EWMA(c) -> H2,H3 -> H_to_matrix -> residual of the current profile -> tridiagonal solve ->
- * validity check.  State arrays are (nb, n) point-fastest and stay resident on the device. */
+ * validity check.  State arrays are (nb, n) point-fastest and stay resident on the device.
+ * The state and parameter blocks are plain structs owned by the caller (there is no create/destroy/get/set: the
+ * caller allocates the arrays, fills in the pointers and may read or replace any array between calls). */
 typedef struct {
     int64_t nb, n;
     double *u;         /* current profile, overwritten with the new iterate */
@@ -219,8 +224,8 @@ enum { TG_TREAD_MAX_HALVINGS = 64 };
 size_t tg_picard_1f_work_bytes(int64_t nb, int64_t n);
 int tg_picard_1f_step(const tg_state_1f *state, const tg_params_1f *params, tg_stream stream);
 
-/* counts[0..3] (device int64): profiles still active, converged, invalid, singular;
- * maxrms (device double): largest last residual among all profiles (NULL to skip). */
+/* counts[0..3] (device int64, zeroed by the call): profiles still active, converged, invalid, singular
+ * (tango/solver.py:404-418: the `ok` property of a whole ensemble). */
 int tg_status_reduce(const int32_t *status, int64_t nb, int64_t *counts, tg_stream stream);
 
 /* ---- fused Picard iteration, three fields n, pi<->pe -------------------------------------------

@@ -530,7 +530,7 @@ extern "C" {
 int tg_pair_solve(const double *AU, const double *BU, const double *CU, const double *DU, const double *GW, const double *AW,
                   const double *BW, const double *CW, const double *DW, const double *GU, double *U, double *W, int64_t nb,
                   int64_t n, int32_t *status, tg_stream stream) {
-    if (nb < 0 || n < 1) return fail(TG_ERR_ARG, "bad dimensions%s");
+    if (int e = check_dims(nb, n, 1)) return e;
     if (!AU || !BU || !CU || !DU || !GW || !AW || !BW || !CW || !DW || !GU || !U || !W) return fail(TG_ERR_ARG, "NULL array%s");
     if (nb == 0) return TG_OK;
     PairArgs a{AU, BU, CU, DU, GW, AW, BW, CW, DW, GU, U, W};
@@ -539,7 +539,7 @@ int tg_pair_solve(const double *AU, const double *BU, const double *CU, const do
 
 int tg_block3_solve(const double *Cb, const double *Bb, const double *Ab, const double *d, double *x, int64_t nb, int64_t n,
                     int32_t *status, tg_stream stream) {
-    if (nb < 0 || n < 1) return fail(TG_ERR_ARG, "bad dimensions%s");
+    if (int e = check_dims(nb, n, 1)) return e;
     if (!Cb || !Bb || !Ab || !d || !x) return fail(TG_ERR_ARG, "NULL array%s");
     if (nb == 0) return TG_OK;
     return dispatch_block<Block3Launcher>(nb, (int)n, 512, S(stream), Cb, Bb, Ab, d, x, status);
@@ -547,7 +547,7 @@ int tg_block3_solve(const double *Cb, const double *Bb, const double *Ab, const 
 
 int tg_picard_3f_step(const tg_state_3f *st, const tg_params_3f *q, tg_stream stream) {
     if (!st || !q) return fail(TG_ERR_ARG, "NULL state or params%s");
-    if (st->nb < 0 || st->n < 3) return fail(TG_ERR_ARG, "bad dimensions%s");
+    if (int e = check_dims(st->nb, st->n, 3)) return e;
     for (int s = 0; s < 3; ++s) {
         if (!st->u[s] || !st->um1[s] || !st->uE[s] || !st->DE[s] || !st->cE[s]) return fail(TG_ERR_ARG, "NULL state array%s");
         if (!q->UL[s] || !q->H7[s]) return fail(TG_ERR_ARG, "UL and H7 are required for the three fields%s");

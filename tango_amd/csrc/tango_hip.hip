@@ -114,41 +114,142 @@ tridiag_pf_kernel(const double *__restrict__ A, const double *__restrict__ B, co
     }
 }
 
-// Tridiagonal solve, batch-fastest: one lane per profile, every access of a sweep coalesced across
-// the batch.  cp (n*nb) holds the forward-sweep multipliers; the modified right-hand side is kept
-// in u and overwritten by the back substitution.
+// Tridiagonal solve, batch-fastest: one lane per profile, every access of a sweep coalesced across the batch.
+//
+// The sweeps are LAPACK dgtsv's (the routine scipy.linalg.solve_banded reaches from tango/tridiag.py:94-96),
+// operation by operation, partial pivoting included, with floating-point contraction switched off: for finite data
+// the result is the reference's bit for bit.  Row i of the forward sweep compares |d_i| with the sub-diagonal entry
+// below it; without an interchange it eliminates with fact = dl_i / d_i, with one it swaps rows i and i+1, which
+// puts an entry on the second super-diagonal (du2).  The pivots d go to the work space and the modified right-hand
+// side to u.  The modified super-diagonal and du2 are written only from the first row on at which some profile of
+// the wavefront needed an interchange (`sw`, uniform over the wavefront); before that row du is the caller's A and
+// du2 is zero, which is every row for the diagonally dominant matrices of the transport problem.
+// U rows are fetched ahead of the arithmetic: the sweeps are one long dependent chain per lane and a batch of
+// 65 536 profiles is one wavefront per SIMD, so nothing else hides the memory latency.
+template <int U>
 __global__ void __launch_bounds__(256)
 tridiag_bf_kernel(const double *__restrict__ A, const double *__restrict__ B, const double *__restrict__ C,
-                  const double *__restrict__ D, double *u, int64_t nb, int n, double *__restrict__ cp,
-                  int32_t *__restrict__ status) {
+                  const double *D, double *u, int64_t nb, int n, double *__restrict__ wd,
+                  double *__restrict__ wdu, double *__restrict__ wdu2, int32_t *__restrict__ status) {
+    // (u may alias D: every row of D is fetched before the same row of u is written, in program order)
+#pragma clang fp contract(off)
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
-    int sing = 0;
-    double den = B[b];
-    sing |= (den == 0.0);
-    double e = (n > 1 ? A[b] : 0.0) / den;
-    double f = D[b] / den;
-    cp[b] = e;
-    u[b] = f;
-    // software prefetch of the next row keeps several loads in flight per lane
-    for (int j = 1; j < n; ++j) {
-        const int64_t k = (int64_t)j * nb + b;
-        const double cj = C[k], bj = B[k], dj = D[k];
-        const double aj = (j < n - 1) ? A[k] : 0.0;
-        den = bj - cj * e;
-        sing |= (den == 0.0);
-        e = aj / den;
-        f = (dj - cj * f) / den;
-        cp[k] = e;
-        u[k] = f;
+    int info = 0;
+    int sw = n;                         // first row whose du / du2 live in the work space
+    double d = B[b], rhs = D[b], du = (n > 1) ? A[b] : 0.0;
+    // rows i+1 .. i+U of C, B, D, A, fetched one block ahead
+    double cq[U], bq[U], dq[U], aq[U];
+    auto fetch = [&](int i0, double (&c_)[U], double (&b_)[U], double (&d_)[U], double (&a_)[U]) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int r = i0 + 1 + q;
+            const bool in = r < n;
+            const int64_t k = (int64_t)(in ? r : n - 1) * nb + b;
+            c_[q] = C[k];
+            b_[q] = B[k];
+            d_[q] = D[k];
+            a_[q] = (r < n - 1) ? A[k] : 0.0;
+        }
+    };
+    fetch(0, cq, bq, dq, aq);
+    for (int i0 = 0; i0 < n - 1; i0 += U) {
+        double cn[U], bn_[U], dn_[U], an[U];
+        if (i0 + U < n - 1) fetch(i0 + U, cn, bn_, dn_, an);
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int i = i0 + q;
+            if (i < n - 1) {
+                const double dl = cq[q];
+                double dnext = bq[q], bnext = dq[q], dunext = aq[q], du2 = 0.0;
+                const bool piv = !(fabs(d) >= fabs(dl));
+                if (sw == n && __any(piv)) sw = i;
+                if (!piv) {
+                    info |= (d == 0.0);
+                    const double fact = dl / d;
+                    dnext = dnext - fact * du;
+                    bnext = bnext - fact * rhs;
+                } else {
+                    const double fact = d / dl;
+                    d = dl;
+                    double temp = dnext;
+                    dnext = du - fact * temp;
+                    if (i < n - 2) {
+                        du2 = dunext;
+                        dunext = -fact * du2;
+                    }
+                    du = temp;
+                    temp = rhs;
+                    rhs = bnext;
+                    bnext = temp - fact * bnext;
+                }
+                const int64_t k = (int64_t)i * nb + b;
+                wd[k] = d;
+                u[k] = rhs;
+                if (i >= sw) {
+                    wdu[k] = du;
+                    wdu2[k] = du2;
+                }
+                d = dnext;
+                rhs = bnext;
+                du = dunext;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            cq[q] = cn[q];
+            bq[q] = bn_[q];
+            dq[q] = dn_[q];
+            aq[q] = an[q];
+        }
     }
-    double x = f;
-    for (int j = n - 2; j >= 0; --j) {
-        const int64_t k = (int64_t)j * nb + b;
-        x = u[k] - cp[k] * x;
-        u[k] = x;
+    info |= (d == 0.0);
+    // back substitution: x_i = (b_i - du_i x_{i+1} - du2_i x_{i+2}) / d_i (no du2 term in the last two rows)
+    double x1 = rhs / d, x2 = 0.0;
+    u[(int64_t)(n - 1) * nb + b] = x1;
+    double pd[U], pb[U], pu[U], p2[U];
+    auto fetch_back = [&](int ihi, double (&d_)[U], double (&b_)[U], double (&u_)[U], double (&v_)[U]) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int r = ihi - q;
+            const int rc = r >= 0 ? r : 0;
+            const int64_t k = (int64_t)rc * nb + b;
+            d_[q] = wd[k];
+            b_[q] = u[k];
+            if (rc >= sw) {
+                u_[q] = wdu[k];
+                v_[q] = wdu2[k];
+            } else {
+                u_[q] = A[k];
+                v_[q] = 0.0;
+            }
+        }
+    };
+    if (n > 1) fetch_back(n - 2, pd, pb, pu, p2);
+    for (int ihi = n - 2; ihi >= 0; ihi -= U) {
+        double nd[U], nbv[U], nu[U], n2[U];
+        if (ihi - U >= 0) fetch_back(ihi - U, nd, nbv, nu, n2);
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int i = ihi - q;
+            if (i >= 0) {
+                double x;
+                if (i == n - 2) x = (pb[q] - pu[q] * x1) / pd[q];
+                else x = (pb[q] - pu[q] * x1 - p2[q] * x2) / pd[q];
+                u[(int64_t)i * nb + b] = x;
+                x2 = x1;
+                x1 = x;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            pd[q] = nd[q];
+            pb[q] = nbv[q];
+            pu[q] = nu[q];
+            p2[q] = n2[q];
+        }
     }
-    if (status && sing) atomicOr(&status[b], TG_ST_SINGULAR);
+    if (status && info) atomicOr(&status[b], TG_ST_SINGULAR);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1020,6 +1121,31 @@ struct Picard1fLauncher {
 
 }  // namespace
 
+// argument checks shared by tg_picard_1f_step and tg_picard_1f_step_static (C++ linkage: not part of the C ABI)
+int tg_picard_1f_validate(const tg_state_1f *st, const tg_params_1f *q) {
+    if (!st || !q) return fail(TG_ERR_ARG, "NULL state or params%s");
+    if (int e = check_dims(st->nb, st->n, 3)) return e;
+    if (!st->u || !st->um1 || !st->uE || !st->DE || !st->cE || !st->status || !st->iters) return fail(TG_ERR_ARG, "NULL state array%s");
+    if (!q->UL) return fail(TG_ERR_ARG, "UL is required%s");
+    if (!q->H7 && (!q->S0 || !q->src_cut)) return fail(TG_ERR_ARG, "either H7 or (S0, src_cut) is required%s");
+    if (q->flux_model == TG_FLUX_EXTERNAL && !q->flux) return fail(TG_ERR_ARG, "external flux model needs a flux array%s");
+    if (q->flux_model != TG_FLUX_EXTERNAL && q->flux_model != TG_FLUX_SHESTAKOV) return fail(TG_ERR_ARG, "unknown flux model%s");
+    if (q->flux_model == TG_FLUX_EXTERNAL && q->iters_per_launch > 1) return fail(TG_ERR_ARG, "an external flux is valid for one iteration only%s");
+    if (q->tread_lightly && !q->pseudo_time) return fail(TG_ERR_ARG, "tread_lightly needs pseudo_time (the previous iterate in the u_{m-1} slot)%s");
+    if (q->tread_lightly && (q->tread_inner_count < 0 || q->tread_inner_count > st->n || !(q->tread_max_change > 0.0)))
+        return fail(TG_ERR_ARG, "tread_lightly needs 0 <= tread_inner_count <= n and tread_max_change > 0%s");
+    if (q->tread_initial_steps < 0 || (q->tread_initial_steps > 0 && (!q->pseudo_time || !(q->tread_initial_dtau > 0.0))))
+        return fail(TG_ERR_ARG, "tread_initial_steps needs pseudo_time and tread_initial_dtau > 0%s");
+    if (q->smooth_window > 1) return fail(TG_ERR_UNSUPPORTED, "flux smoothing is not fused; smooth the flux with tg_moving_average and pass it as an external flux%s");
+    if (st->err && st->err_stride <= 0) return fail(TG_ERR_ARG, "err_stride must be positive%s");
+    if (q->iterates && q->iterates_rows < 0) return fail(TG_ERR_ARG, "iterates_rows must not be negative%s");
+    return TG_OK;
+}
+
+int tg_picard_1f_dispatch(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
+    return dispatch_group<Picard1fLauncher, true>(st->nb, (int)st->n, s, st, q);
+}
+
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
@@ -1066,14 +1192,8 @@ int tg_stream_create(tg_stream *stream) {
 int tg_stream_destroy(tg_stream stream) { TG_HIP(hipStreamDestroy(S(stream))); return TG_OK; }
 int tg_stream_sync(tg_stream stream) { TG_HIP(hipStreamSynchronize(S(stream))); return TG_OK; }
 
-static int check_dims(int64_t nb, int64_t n, int64_t nmin) {
-    if (nb < 0 || n < nmin) return fail(TG_ERR_ARG, "bad dimensions (nb >= 0, n >= minimum for this operation)%s");
-    if (n > (int64_t)1 << 30) return fail(TG_ERR_ARG, "n too large%s");
-    return TG_OK;
-}
-
 size_t tg_tridiag_work_bytes(int64_t nb, int64_t n, int layout) {
-    return layout == TG_BATCH_FASTEST ? sizeof(double) * (size_t)nb * (size_t)n : 0;
+    return layout == TG_BATCH_FASTEST ? 3 * sizeof(double) * (size_t)nb * (size_t)n : 0;     // pivots, du, du2
 }
 
 int tg_tridiag_solve(const double *A, const double *B, const double *C, const double *D, double *u, int64_t nb, int64_t n,
@@ -1083,8 +1203,10 @@ int tg_tridiag_solve(const double *A, const double *B, const double *C, const do
     if (nb == 0) return TG_OK;
     if (layout == TG_BATCH_FASTEST) {
         if (!work || work_bytes < tg_tridiag_work_bytes(nb, n, layout)) return fail(TG_ERR_ARG, "work space too small%s");
-        hipLaunchKernelGGL(tridiag_bf_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, S(stream), A, B, C, D, u, nb,
-                           (int)n, (double *)work, status);
+        if (u == A || u == B || u == C) return fail(TG_ERR_ARG, "batch-fastest solve: u may alias D only%s");
+        double *wd = (double *)work, *wdu = wd + nb * n, *wdu2 = wdu + nb * n;
+        hipLaunchKernelGGL(tridiag_bf_kernel<8>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, S(stream), A, B, C, D, u, nb,
+                           (int)n, wd, wdu, wdu2, status);
         return launch_check();
     }
     if (layout != TG_POINT_FASTEST) return fail(TG_ERR_ARG, "unknown layout%s");
@@ -1184,25 +1306,10 @@ int tg_shestakov_flux(const double *nprof, double dx, double *flux, int64_t nb, 
 size_t tg_picard_1f_work_bytes(int64_t nb, int64_t n) { return (nb > 0 && n > 0) ? tg_seg_work_bytes(nb, n) : 0; }
 
 int tg_picard_1f_step(const tg_state_1f *st, const tg_params_1f *q, tg_stream stream) {
-    if (!st || !q) return fail(TG_ERR_ARG, "NULL state or params%s");
-    if (int e = check_dims(st->nb, st->n, 3)) return e;
-    if (!st->u || !st->um1 || !st->uE || !st->DE || !st->cE || !st->status || !st->iters) return fail(TG_ERR_ARG, "NULL state array%s");
-    if (!q->UL) return fail(TG_ERR_ARG, "UL is required%s");
-    if (!q->H7 && (!q->S0 || !q->src_cut)) return fail(TG_ERR_ARG, "either H7 or (S0, src_cut) is required%s");
-    if (q->flux_model == TG_FLUX_EXTERNAL && !q->flux) return fail(TG_ERR_ARG, "external flux model needs a flux array%s");
-    if (q->flux_model != TG_FLUX_EXTERNAL && q->flux_model != TG_FLUX_SHESTAKOV) return fail(TG_ERR_ARG, "unknown flux model%s");
-    if (q->flux_model == TG_FLUX_EXTERNAL && q->iters_per_launch > 1) return fail(TG_ERR_ARG, "an external flux is valid for one iteration only%s");
-    if (q->tread_lightly && !q->pseudo_time) return fail(TG_ERR_ARG, "tread_lightly needs pseudo_time (the previous iterate in the u_{m-1} slot)%s");
-    if (q->tread_lightly && (q->tread_inner_count < 0 || q->tread_inner_count > st->n || !(q->tread_max_change > 0.0)))
-        return fail(TG_ERR_ARG, "tread_lightly needs 0 <= tread_inner_count <= n and tread_max_change > 0%s");
-    if (q->tread_initial_steps < 0 || (q->tread_initial_steps > 0 && (!q->pseudo_time || !(q->tread_initial_dtau > 0.0))))
-        return fail(TG_ERR_ARG, "tread_initial_steps needs pseudo_time and tread_initial_dtau > 0%s");
-    if (q->smooth_window > 1) return fail(TG_ERR_UNSUPPORTED, "flux smoothing is not fused; smooth the flux with tg_moving_average and pass it as an external flux%s");
-    if (st->err && st->err_stride <= 0) return fail(TG_ERR_ARG, "err_stride must be positive%s");
-    if (q->iterates && q->iterates_rows < 0) return fail(TG_ERR_ARG, "iterates_rows must not be negative%s");
+    if (int e = tg_picard_1f_validate(st, q)) return e;
     if (st->nb == 0) return TG_OK;
     if (tg_seg_applies(st, q)) return tg_seg_step(st, q, S(stream));
-    return dispatch_group<Picard1fLauncher, true>(st->nb, (int)st->n, S(stream), st, q);
+    return tg_picard_1f_dispatch(st, q, S(stream));
 }
 
 int tg_stream_probe(const double *const in[5], double *const out[4], int64_t count, tg_stream stream) {

@@ -12,6 +12,9 @@ extern thread_local char tg_err_buf[512];
 size_t tg_seg_work_bytes(int64_t nb, int64_t n);
 bool tg_seg_applies(const tg_state_1f *st, const tg_params_1f *q);
 int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s);
+// argument checks and the non-segmented launch of the one-field step (tango_hip.hip)
+int tg_picard_1f_validate(const tg_state_1f *st, const tg_params_1f *q);
+int tg_picard_1f_dispatch(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s);
 
 namespace {
 
@@ -31,6 +34,13 @@ inline hipStream_t S(tg_stream s) { return reinterpret_cast<hipStream_t>(s); }
 inline int launch_check() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(TG_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return TG_OK;
+}
+
+// dimensions every entry point accepts: the kernels index a profile with 32-bit integers
+inline int check_dims(int64_t nb, int64_t n, int64_t nmin) {
+    if (nb < 0 || n < nmin) return fail(TG_ERR_ARG, "bad dimensions (nb >= 0, n >= minimum for this operation)%s");
+    if (n > (int64_t)1 << 30) return fail(TG_ERR_ARG, "n too large%s");
     return TG_OK;
 }
 
