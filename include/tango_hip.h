@@ -224,6 +224,19 @@ enum { TG_TREAD_MAX_HALVINGS = 64 };
 size_t tg_picard_1f_work_bytes(int64_t nb, int64_t n);
 int tg_picard_1f_step(const tg_state_1f *state, const tg_params_1f *params, tg_stream stream);
 
+/* The same step for callers that cannot allocate device memory (code under HIP graph capture, serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  It is tg_picard_1f_step for the profile
+ * lengths whose step needs a work space (n = 8192, 16384, 32768; built-in flux, Cartesian, one iteration per call),
+ * with params->work ignored: the work space is a TG_STATIC_WORK_BYTES array inside the library, one per GPU, held
+ * until the process ends.  tg_picard_1f_work_bytes(nb, n) must not exceed TG_STATIC_WORK_BYTES (about 4.4 million
+ * grid points in all, e.g. 512 x 8192); larger ensembles get TG_ERR_ARG, other profile lengths TG_ERR_UNSUPPORTED
+ * (they need no work space: tg_picard_1f_step allocates nothing for them either).  The call allocates and frees
+ * nothing; the first call on a device looks up the array's address (make it outside graph capture).  All calls
+ * on one GPU share that array: calls that overlap in time on one GPU (different streams or threads) race; calls
+ * ordered on one stream are safe, every call clears what it needs cleared. */
+enum { TG_STATIC_WORK_BYTES = 36 * 1024 * 1024 };
+int tg_picard_1f_step_static(const tg_state_1f *state, const tg_params_1f *params, tg_stream stream);
+
 /* counts[0..3] (device int64, zeroed by the call): profiles still active, converged, invalid, singular
  * (tango/solver.py:404-418: the `ok` property of a whole ensemble). */
 int tg_status_reduce(const int32_t *status, int64_t nb, int64_t *counts, tg_stream stream);

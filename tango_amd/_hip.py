@@ -16,6 +16,7 @@ TG_OK, TG_ERR_ARG, TG_ERR_HIP, TG_ERR_UNSUPPORTED = 0, 1, 2, 3
 POINT_FASTEST, BATCH_FASTEST = 0, 1
 ST_CONVERGED, ST_INVALID, ST_SINGULAR, ST_SEEDED, ST_TREAD_LIMIT = 1, 2, 4, 8, 16
 FLUX_SHESTAKOV, FLUX_EXTERNAL = 0, 1
+STATIC_WORK_BYTES = 36 * 1024 * 1024
 
 
 class HipError(RuntimeError):
@@ -101,6 +102,7 @@ PROTOTYPES = {
     'tg_pair_solve': (_int, [_p] * 12 + [_i64, _i64, _p, _p]),
     'tg_block3_solve': (_int, [_p, _p, _p, _p, _p, _i64, _i64, _p, _p]),
     'tg_picard_1f_step': (_int, [C.POINTER(State1F), C.POINTER(Params1F), _p]),
+    'tg_picard_1f_step_static': (_int, [C.POINTER(State1F), C.POINTER(Params1F), _p]),
     'tg_status_reduce': (_int, [_p, _i64, _p, _p]),
     'tg_picard_3f_step': (_int, [C.POINTER(State3F), C.POINTER(Params3F), _p]),
 }

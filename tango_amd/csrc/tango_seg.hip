@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/tango_hip.h"
 #include "tg_assemble.h"
 #include "tg_comm.h"
@@ -451,4 +453,53 @@ int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
     }
     hipLaunchKernelGGL((picard_seg_kernel<1>), dim3(grid), dim3(256), lds1, s, *st, *q, W);
     return launch_check();
+}
+
+// ------------------------------------------------------------------------------------------
+// The same step with the work space inside the library, for callers that cannot allocate.
+// ------------------------------------------------------------------------------------------
+// One copy of this array exists on every GPU the library is loaded on, until the process ends.  In host code the
+// name `scratch` only identifies the symbol: the device address is looked up once per device with
+// hipGetSymbolAddress and every launch and memset below is handed that address.
+static __device__ __align__(256) unsigned char scratch[TG_STATIC_WORK_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+void *scratch_ptr[kMaxDevices] = {};      // device address of `scratch` on each device, resolved on first use
+std::mutex scratch_mutex;
+
+int scratch_on_current_device(void **out) {
+    int dev = -1;
+    TG_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(TG_ERR_UNSUPPORTED, "device ordinal beyond the library's table%s");
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (!scratch_ptr[dev]) {
+        void *p = nullptr;
+        TG_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(TG_ERR_HIP, "hipGetSymbolAddress returned a null address%s");
+        scratch_ptr[dev] = p;
+    }
+    *out = scratch_ptr[dev];
+    return TG_OK;
+}
+}  // namespace
+
+extern "C" int tg_picard_1f_step_static(const tg_state_1f *st, const tg_params_1f *q, tg_stream stream) {
+    if (int e = tg_picard_1f_validate(st, q)) return e;
+    const size_t need = tg_seg_work_bytes(st->nb, st->n);
+    if (need == 0) return fail(TG_ERR_UNSUPPORTED, "tg_picard_1f_step_static steps profiles of 8192, 16384 or 32768 points (the sizes "
+                                                   "whose step uses a work space); other sizes need none: call tg_picard_1f_step%s");
+    if (need > (size_t)TG_STATIC_WORK_BYTES)
+        return fail(TG_ERR_ARG, "tg_picard_1f_step_static: nb*n exceeds what the library's built-in work space of TG_STATIC_WORK_BYTES holds "
+                                "(about 4.4 million grid points in all, e.g. 512 profiles of 8192 points)%s");
+    if (st->nb == 0) return TG_OK;
+    void *ws = nullptr;
+    if (int e = scratch_on_current_device(&ws)) return e;
+    tg_params_1f p = *q;
+    p.work = ws;
+    p.work_bytes = TG_STATIC_WORK_BYTES;
+    if (!tg_seg_applies(st, &p))
+        return fail(TG_ERR_UNSUPPORTED, "tg_picard_1f_step_static: the segmented step needs the built-in flux, Cartesian geometry, one "
+                                        "iteration per call, no pseudo-timestep control, no iterate history and 16-byte aligned arrays%s");
+    return tg_seg_step(st, &p, S(stream));
 }
