@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
-"""Benchmark of the fused Picard iteration on the synthetic Shestakov ensemble.
+"""Benchmark of the fused Picard iteration on the synthetic ensembles of the benchmark set.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config metric|c2|c3|c4] [--iters-per-launch k]
 
-One "step" = one Picard iteration (EWMA -> flux -> split -> EWMA -> assembly -> residual -> tridiagonal
-solve -> validity check) of every profile of the ensemble, all profiles forced active.  --iters-per-launch k
-(default 64) runs k consecutive steps in one kernel launch with every profile held in registers in between: the
-arithmetic, the per-iteration convergence test and the residual history are those of k single launches, only
-the HBM round trip of the state between iterations is gone (k = 1 gives the one-launch-per-iteration form).  Each GPU (one
-process per GPU; for N > 1 launch through torch.distributed.run) holds 65 536 profiles x 512 grid points,
-fp64, resident in HBM before the timed region; the batch shards with no data exchange, the only collective is
-the all-reduce of the convergence counters (RCCL), issued every --check-every steps inside the timed region.
+One "step" = one Picard iteration (EWMA -> flux -> split -> EWMA -> assembly -> residual -> solve -> validity
+check) of every profile of the ensemble, all profiles forced active.  Configurations (per GPU):
+  metric  one field, 65 536 profiles x 512 points, EWMA 0.3/1.0, dt = 1e4       (the headline workload)
+  c2      one field, 65 536 x 256
+  c3      three fields n, pi<->pe with nonlinear nu, 16 384 x 512, EWMA 0.3/0.3, dt = 1e6
+  c4      one field, 4 096 x 8192, EWMA 0.3/0.3 (segmented form of the step)
+--iters-per-launch k (one-field configurations up to 512 points; default 64 for metric and c2) runs k consecutive
+steps in one kernel launch with every profile held in registers in between: the arithmetic, the per-iteration
+convergence test and the residual history are those of k single launches, only the HBM round trip of the state
+between iterations is gone.
 
-Rank 0 prints ONE JSON line.  `value` is in units of "Picard iterations per second of a 65 536-profile
-ensemble": (profiles on all GPUs / 65 536) x steps / time, so that at N = 1 it is literally the iteration rate
-of the 64K-profile ensemble the metric names and at N GPUs the aggregate of N such shards (weak scaling).
+N > 1: one process per GPU.  Started by a launcher (RANK / WORLD_SIZE in the environment, e.g.
+torch.distributed.run) every process is one rank; started plainly with --gpus N this process starts the N ranks
+itself, before it touches any GPU, and relays rank 0's line.  The ensemble shards with no data exchange
+(weak scaling: every GPU holds a full-size shard); the only collectives are the all-reduces of the convergence
+counters and of the residual summary (RCCL), issued every --check-every steps inside the timed region; their
+result, read one check later so that the host never waits for the GPU, decides whether the loop goes on.
+
+Rank 0 prints ONE JSON line.  `value` is in "Picard iterations per second of a full-size ensemble": (profiles on
+all GPUs / profiles per GPU of the configuration) x steps / time.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,21 +37,58 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E nominal peak
-BYTES_PER_POINT = 72           # 5 arrays read + 4 written per point per iteration, fp64
-PROFILES_PER_GPU = 65536
-N_GRID = 512
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E nominal peak
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop (fma) x 2.4 GHz
+CLOCK_HZ = 2.4e9
+SIMDS = 1024
+CONFIGS = {
+    #          fields  profiles  n     a_prof  dt    bytes/point  default k
+    'metric': (1,      65536,    512,  1.0,    1e4,  72,          64),
+    'c2':     (1,      65536,    256,  1.0,    1e4,  72,          64),
+    'c3':     (3,      16384,    512,  0.3,    1e6,  216,         1),
+    'c4':     (1,      4096,     8192, 0.3,    1e4,  72,          1),
+}
+METRIC = 'Picard iters/sec, 64K-profile Shestakov ensemble N=512 fp64; % of HBM peak'
 
 
-def cpu_baseline(n, seconds=12.0):
-    """The CPU restatement of the same iteration (oracle/tango_oracle.c, OpenMP over profiles) on a 4096-profile
-    subsample of the same ensemble, timed on this host.  Checker code used as a reported baseline only."""
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """Start n fresh rank processes of this script (no GPU call has been made in this process) and relay rank 0's
+    JSON line.  Returns the exit code for this process."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in (out or '').splitlines():
+        print(line, flush=True)
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f'bench.py: rank(s) failed: {bad}', file=sys.stderr)
+        return 1
+    return 0
+
+
+def cpu_baseline_1f(nprof, n, a_prof, seconds):
+    """The CPU restatement of the same iteration (oracle/tango_oracle.c, OpenMP over profiles) on a subsample of the
+    same ensemble, timed on this host.  Checker code used as a reported baseline only."""
     from oracle import c_oracle
     from tango_amd.ensemble import shestakov_ensemble
-    sub = 4096
-    ens = shestakov_ensemble(PROFILES_PER_GPU, n, lo=0, hi=sub)
+    sub = max(16, min(nprof, (4096 * 512) // n))
+    ens = shestakov_ensemble(nprof, n, lo=0, hi=sub)
     threads = min(16, os.cpu_count() or 1)
-    E = c_oracle.Ensemble1F(ens, fixed_count=True, max_iter=1)
+    E = c_oracle.Ensemble1F(ens, a_prof=a_prof, fixed_count=True, max_iter=1)
     used = E.step(threads)                       # warm-up, also reports the thread count
     t0 = time.perf_counter()
     steps = 0
@@ -51,31 +98,57 @@ def cpu_baseline(n, seconds=12.0):
         el = time.perf_counter() - t0
         if el >= seconds:
             break
-    rate = steps * sub / PROFILES_PER_GPU / el
-    faithful = cpu_faithful(n)
-    return {'value': rate, 'unit': 'iters/s (65536-profile ensemble equivalents)', 'cores': int(used), 'kind': 'port',
-            'sample': f'{steps} iterations of the first {sub} of the 65536 profiles, N={n}, {el:.1f} s wall, '
+    rate = steps * sub / nprof / el
+    return {'value': rate, 'unit': f'iters/s ({nprof}-profile ensemble equivalents)', 'cores': int(used), 'kind': 'port',
+            'sample': f'{steps} iterations of the first {sub} of the {nprof} profiles, N={n}, {el:.1f} s wall, '
                       f'C restatement of the reference path (oracle/tango_oracle.c), OpenMP {used} threads',
-            'profile_iterations_per_s': steps * sub / el, 'faithful_numpy': faithful}
+            'profile_iterations_per_s': steps * sub / el, 'faithful_numpy': cpu_faithful_1f(nprof, n, a_prof)}
 
 
-def cpu_faithful(n, seconds=3.0):
+def cpu_faithful_1f(nprof, n, a_prof, seconds=3.0):
     """The reference's own shape of the computation: one profile at a time on one core, NumPy expressions and
     SciPy's banded solver (oracle/tango_oracle.py), for a few seconds on member 0 of the ensemble."""
     from oracle import tango_oracle as orc
     from tango_amd.ensemble import shestakov_ensemble
-    ens = shestakov_ensemble(PROFILES_PER_GPU, n, lo=0, hi=1)
+    ens = shestakov_ensemble(nprof, n, lo=0, hi=1)
     st = orc.State1F(ens['u0'][0])
     H1 = np.ones(n)
     H7 = ens['S0'][0] * (ens['x'] < ens['delta'][0])
     t0 = time.perf_counter()
     steps = 0
     while time.perf_counter() - t0 < seconds:
-        orc.picard_step_1f(st, 1e4, ens['dx'], ens['nL'][0], H1, H7, 0.3, 1.0)
+        orc.picard_step_1f(st, 1e4, ens['dx'], ens['nL'][0], H1, H7, 0.3, a_prof)
         steps += 1
     el = time.perf_counter() - t0
     return {'profile_iterations_per_s': steps / el, 'cores': 1,
             'sample': f'{steps} iterations of member 0, N={n}, {el:.1f} s, NumPy + scipy.linalg.solve_banded one profile at a time'}
+
+
+def cpu_baseline_3f(nprof, n, seconds):
+    """Three fields: the NumPy restatement (oracle/tango_oracle.py: two LAPACK band solves per iteration, as the
+    reference) on member 0, one core."""
+    from oracle import tango_oracle as orc
+    from tango_amd.ensemble import threefield_ensemble
+    ens = threefield_ensemble(nprof, n, lo=0, hi=1)
+    st = orc.State3F(ens['u0'][0], ens['u0'][0], ens['u0'][0])
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < seconds:
+        orc.picard_step_3f(st, 1e6, ens['dx'], ens['bc'][0], ens['nu0'][0], ens['x'], 0.3, 0.3)
+        steps += 1
+    el = time.perf_counter() - t0
+    return {'value': steps / el / nprof, 'unit': f'iters/s ({nprof}-profile ensemble equivalents)', 'cores': 1, 'kind': 'port',
+            'sample': f'{steps} iterations of member 0 of the three-field ensemble, N={n}, {el:.1f} s wall, NumPy restatement '
+                      f'(oracle/tango_oracle.py) with scipy.linalg.solve_banded, one profile at a time on one core',
+            'profile_iterations_per_s': steps / el}
+
+
+def committed(key):
+    """A number from the committed rocprofv3 counter passes (profiles/traffic.json), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get(key)
+    except Exception:
+        return None
 
 
 def main():
@@ -83,53 +156,81 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=192)
     ap.add_argument('--warmup', type=int, default=64)
-    ap.add_argument('--iters-per-launch', type=int, default=64,
-                    help='Picard iterations per kernel launch (profiles stay in registers in between); 1 = one launch per step')
-    ap.add_argument('--check-every', type=int, default=64, help='steps between convergence-counter all-reduces')
-    ap.add_argument('--profiles-per-gpu', type=int, default=PROFILES_PER_GPU)
-    ap.add_argument('--n', type=int, default=N_GRID)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='metric')
+    ap.add_argument('--iters-per-launch', type=int, default=0,
+                    help='Picard iterations per kernel launch (profiles stay in registers in between); 0 = the configuration\'s default')
+    ap.add_argument('--check-every', type=int, default=64, help='steps between convergence all-reduces')
+    ap.add_argument('--profiles-per-gpu', type=int, default=0)
+    ap.add_argument('--n', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        raise SystemExit('bench.py: --gpus and --steps must be positive, --warmup non-negative')
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))         # nothing in this process has touched a GPU
 
     import torch
     import torch.distributed as dist
     import tango_amd
     from tango_amd import _hip as H
     from tango_amd import distributed as D
-    from tango_amd.ensemble import OneFieldEnsemble, shard_range, shestakov_ensemble
+    from tango_amd.ensemble import OneFieldEnsemble, ThreeFieldEnsemble, shard_range, shestakov_ensemble, threefield_ensemble
 
     rank, world, local = D.init_from_env()
-    if world != args.gpus and rank == 0:
-        print(f'warning: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks', file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f'bench.py: rank {rank} needs GPU {local} but {torch.cuda.device_count()} are visible')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     stream = torch.cuda.current_stream()
     H.set_stream(stream.cuda_stream)
 
-    nb_total = args.profiles_per_gpu * world
-    lo, hi = shard_range(nb_total, rank, world)
-    ens = shestakov_ensemble(nb_total, args.n, lo=lo, hi=hi)
-    alloc = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=dev)     # torch owns the state pool
-    E = OneFieldEnsemble(ens, a_turb=0.3, a_prof=1.0, tol=1e-11, fixed_count=True, keep_err=False, alloc=alloc)
-    counts = torch.zeros(4, dtype=torch.int64, device=dev)      # all-reduced over ranks by RCCL
-
-    kper = max(1, args.iters_per_launch)
+    fields, per_gpu, n, a_prof, dt, bpp, kdef = CONFIGS[args.config]
+    per_gpu = args.profiles_per_gpu or per_gpu
+    n = args.n or n
+    kper = max(1, args.iters_per_launch or kdef)
+    if fields == 3 or n > 512:
+        kper = 1                                   # these kernels run one iteration per launch
     check = max(kper, args.check_every - args.check_every % kper)
+    k1_steps = max(8, args.steps // 4) if kper > 1 else 0
+    rows = args.warmup + args.steps + k1_steps + 8  # residual history columns: every iteration of this run
+    nb_total = per_gpu * world
+    lo, hi = shard_range(nb_total, rank, world)
+    alloc = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=dev)     # torch owns the state pool
+    if fields == 1:
+        ens = shestakov_ensemble(nb_total, n, lo=lo, hi=hi)
+        E = OneFieldEnsemble(ens, dt=dt, a_turb=0.3, a_prof=a_prof, tol=1e-11, fixed_count=True, keep_err=True, max_iter=rows, alloc=alloc)
+    else:
+        ens = threefield_ensemble(nb_total, n, lo=lo, hi=hi)
+        E = ThreeFieldEnsemble(ens, dt=dt, a_turb=0.3, a_prof=a_prof, tol=1e-9, fixed_count=True, keep_err=True, max_iter=rows, alloc=alloc)
+    mon = D.ConvergenceMonitor(E, dev, stream)     # device reductions + RCCL all-reduces + asynchronous copy to the host
+
+    def nothing_left():
+        """The previous check's verdict (all ranks see the same reduced numbers): True when no profile anywhere
+        still iterates.  Its copy landed long ago: a whole check interval of launches has been queued behind it."""
+        res = mon.previous()
+        return res is not None and res['active'] == 0.0
 
     def run(nsteps):
-        """nsteps Picard iterations: launches of kper iterations (a shorter one at the end if needed), the
-        convergence counters reduced on the device and all-reduced over the ranks every `check` steps."""
+        """Up to nsteps Picard iterations: launches of kper iterations (a shorter one at the end if needed), a
+        convergence check every `check` steps; the loop ends early when a check found nothing left to iterate."""
         done = 0
         while done < nsteps:
             k = min(kper, nsteps - done)
             E.step(stream.cuda_stream, iters=k)
             done += k
             if done % check == 0:
-                E.reduce_status(stream.cuda_stream, counts.data_ptr())
-                D.allreduce_counts(counts)
+                if nothing_left():
+                    break
+                mon.issue()
+        return done
 
     def fence():
         if world > 1:
@@ -137,83 +238,116 @@ def main():
         torch.cuda.synchronize()
 
     run(args.warmup)
-    E.reduce_status(stream.cuda_stream, counts.data_ptr())      # whatever the warm-up length: the collective has run once
-    D.allreduce_counts(counts)
+    mon.issue()                  # whatever the warm-up length: both collectives have run once before the timed region
+    mon.previous()
     fence()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    issued_before = mon.issued
     t0 = time.perf_counter()
     e0.record(stream)
-    run(args.steps)
+    done = run(args.steps)
     e1.record(stream)
     fence()
     wall = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
+    if done != args.steps:
+        raise SystemExit(f'bench.py: the timed region ended after {done} of {args.steps} steps')
+    timed_checks = mon.issued - issued_before
 
-    # the same step with one iteration per launch (every iteration crosses HBM), reported beside the headline
-    k1_steps = max(8, args.steps // 4)
-    for _ in range(3):
-        E.step(stream.cuda_stream, iters=1)
-    fence()
-    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s0.record(stream)
-    for _ in range(k1_steps):
-        E.step(stream.cuda_stream, iters=1)
-    s1.record(stream)
-    fence()
-    k1_ms = s0.elapsed_time(s1) / k1_steps
+    # the same step with one iteration per launch (every iteration crosses HBM): the HBM roofline of the path
+    k1_ms = None
+    if kper > 1:
+        for _ in range(3):
+            E.step(stream.cuda_stream, iters=1)
+        fence()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record(stream)
+        for _ in range(k1_steps):
+            E.step(stream.cuda_stream, iters=1)
+        s1.record(stream)
+        fence()
+        k1_ms = s0.elapsed_time(s1) / k1_steps
 
-    t = torch.tensor([wall, ev_ms, k1_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([wall, ev_ms, k1_ms or 0.0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall, ev_ms, k1_ms = float(t[0]), float(t[1]), float(t[2])
+    wall, ev_ms, k1_max = float(t[0]), float(t[1]), float(t[2])
     bad = int(np.count_nonzero(E.status.to_host() & 6))
+    mon.issue()
+    red = mon.previous()
 
     if rank == 0:
+        shard = hi - lo
         ms_per_step = wall * 1e3 / args.steps
-        value = (nb_total / PROFILES_PER_GPU) * args.steps / wall
+        value = (nb_total / per_gpu) * args.steps / wall
         launches = (args.steps + kper - 1) // kper
-        bytes_per_launch = (hi - lo) * args.n * BYTES_PER_POINT * args.steps / launches
         kernel_ms = ev_ms / launches            # launches are back to back on one stream: events bracket them
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = traffic1 = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath):        # HBM bytes per launch from the committed rocprofv3 counter passes
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(f'picard_1f_{args.profiles_per_gpu}x{args.n}_k{kper}')
-                traffic1 = tj.get(f'picard_1f_{args.profiles_per_gpu}x{args.n}_k1')
-            except Exception:
-                traffic = traffic1 = None
-        k1_bytes = (hi - lo) * args.n * BYTES_PER_POINT
-        k1_achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
+        bytes_per_iter = shard * n * bpp
+        tag = f'{args.config}_{per_gpu}x{n}'
+        hbm_k1 = None
+        if kper == 1:
+            achieved = bytes_per_iter / (kernel_ms * 1e-3) / 1e9
+            roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                        'traffic': committed(f'{tag}_k1_hbm_bytes_per_launch'),
+                        'kernel': 'picard_3f_kernel' if fields == 3 else ('picard_seg_kernel<0>, picard_seg_reduce_kernel, picard_seg_kernel<1>, '
+                                                                         'seg_halo_kernel (one step)' if n > 4096 else 'picard_1f_kernel'),
+                        'kernel_ms': kernel_ms, 'iterations_per_launch': 1, 'algorithmic_bytes_per_launch': bytes_per_iter,
+                        'note': f'algorithmic bytes = {bpp} B/point/iteration x {shard} profiles x {n} points'}
+        else:
+            # k iterations per launch: the state stays in registers, HBM is idle most of the time and the kernel is bound by
+            # fp64 vector issue.  Executed fp64 operations per wavefront-iteration come from the committed rocprofv3 pass
+            # (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 over a launch of the same shape; an fma counts two).
+            flops_wave_iter = committed(f'{tag}_fp64_flops_per_wave_iteration')
+            valu_wave_iter = committed(f'{tag}_valu_insts_per_wave_iteration')
+            waves = -(-shard * n // 512)              # one wavefront per 512 grid points
+            roofline = {'bound': 'valu_fp64', 'achieved': None, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': None,
+                        'traffic': committed(f'{tag}_k{kper}_hbm_bytes_per_launch'), 'kernel': 'picard_1f_kernel (multi-iteration form)',
+                        'kernel_ms': kernel_ms, 'iterations_per_launch': args.steps / launches}
+            if flops_wave_iter:
+                tf = flops_wave_iter * 64 * waves * (args.steps / launches) / (kernel_ms * 1e-3) / 1e12
+                roofline.update(achieved=tf, frac=tf / FP64_VECTOR_PEAK_TFLOPS, fp64_flops_per_wave_iteration=flops_wave_iter)
+            if valu_wave_iter:
+                # every VALU instruction occupies its SIMD for at least 4 cycles (64 lanes over 16 ALUs)
+                roofline['valu_issue_frac'] = valu_wave_iter * 4 * waves * (args.steps / launches) / (SIMDS * kernel_ms * 1e-3 * CLOCK_HZ)
+            roofline['note'] = ('k iterations per launch keep the profiles in registers: HBM traffic per launch (traffic) is that of ONE '
+                                'iteration, so the HBM roofline does not bound this kernel; achieved = executed fp64 operations / kernel time')
+            k1_achieved = bytes_per_iter / (k1_max * 1e-3) / 1e9
+            hbm_k1 = {'bound': 'hbm', 'achieved': k1_achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': k1_achieved / HBM_PEAK_GBS,
+                      'traffic': committed(f'{tag}_k1_hbm_bytes_per_launch'), 'kernel': 'picard_1f_kernel (single-iteration form)',
+                      'kernel_ms': k1_max, 'iters_per_s': (nb_total / per_gpu) * 1e3 / k1_max, 'steps': k1_steps,
+                      'algorithmic_bytes_per_launch': bytes_per_iter,
+                      'note': 'the same step, one Picard iteration per launch: the state crosses HBM every iteration (72 B/point)'}
+        what = {1: f'one-field Shestakov ensemble, {per_gpu} profiles x N={n} per GPU, EWMA 0.3/{a_prof}, dt={dt:g}, fused assemble+solve',
+                3: f'three-field (n, pi<->pe, nonlinear nu) ensemble, {per_gpu} profiles x N={n} per GPU, EWMA 0.3/{a_prof}, dt={dt:g}, '
+                   f'fused assemble + scalar and 2x2 block solves'}[fields]
         out = {
-            'metric': 'Picard iters/sec, 64K-profile Shestakov ensemble N=512 fp64; % of HBM peak',
+            'metric': METRIC if args.config == 'metric' else f'Picard iters/sec, configuration {args.config}; % of HBM peak',
             'value': value,
-            'unit': 'iters/s (65536-profile ensemble equivalents)',
+            'unit': f'iters/s ({per_gpu}-profile ensemble equivalents)',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'one-field Shestakov ensemble, {args.profiles_per_gpu} profiles x N={args.n} per GPU, '
-                                   f'EWMA 0.3/1.0, dt=1e4, fused assemble+solve, all profiles active, seed 12345',
-                       'profiles_total': nb_total, 'grid_points': args.n, 'check_every': check,
-                       'iters_per_launch': kper,
-                       'parallelism': f'batch sharded over {world} GPU(s), RCCL all-reduce of 4 int64 counters'},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'picard_1f_kernel', 'kernel_ms': kernel_ms, 'iterations_per_launch': kper,
-                         'algorithmic_bytes_per_launch': bytes_per_launch,
-                         'note': 'algorithmic bytes = 72 B/point/iteration x iterations per launch; with more than one '
-                                 'iteration per launch the profiles stay in registers between iterations, so HBM traffic '
-                                 '(see traffic) is below the algorithmic bytes and frac can exceed what HBM alone allows'},
-            'single_iteration_launch': {'kernel_ms': k1_ms, 'iters_per_s': (nb_total / PROFILES_PER_GPU) * 1e3 / k1_ms,
-                                        'achieved': k1_achieved, 'frac': k1_achieved / HBM_PEAK_GBS, 'unit': 'GB/s',
-                                        'traffic': traffic1, 'steps': k1_steps,
-                                        'note': 'one Picard iteration per launch: the state crosses HBM every iteration'},
+            'config': {'workload': what + ', all profiles active, seeds as in tango_amd.ensemble',
+                       'name': args.config, 'profiles_total': nb_total, 'grid_points': n,
+                       'launch_shape': {'iterations_per_launch': kper, 'launches_in_timed_region': launches,
+                                        'iterations_in_last_launch': args.steps - (launches - 1) * kper,
+                                        'check_every': check, 'all_reduce_rounds_in_timed_region': timed_checks,
+                                        'reduced_results_consumed': mon.consumed},
+                       'parallelism': f'batch sharded over {world} GPU(s); RCCL all-reduce of 4 int64 counters + 5 fp64 residual '
+                                      f'summary values per check' if world > 1 else 'one GPU (no collective traffic)'},
+            'roofline': roofline,
+            'convergence_summary_last_check': {k: (float(v) if v is not None else None) for k, v in red.items()},
             'invalid_profiles': bad,
         }
+        if hbm_k1:
+            out['hbm_roofline_single_iteration_launch'] = hbm_k1
+            out['hbm_frac_headline'] = hbm_k1['frac']
+        else:
+            out['hbm_frac_headline'] = roofline['frac']
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.n, args.cpu_seconds)
+            out['cpu_baseline'] = cpu_baseline_3f(per_gpu, n, args.cpu_seconds) if fields == 3 else \
+                cpu_baseline_1f(per_gpu, n, a_prof, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(device_ids=[local])

@@ -241,6 +241,15 @@ int tg_picard_1f_step_static(const tg_state_1f *state, const tg_params_1f *param
  * (tango/solver.py:404-418: the `ok` property of a whole ensemble). */
 int tg_status_reduce(const int32_t *status, int64_t nb, int64_t *counts, tg_stream stream);
 
+/* Residual summary of an ensemble, the quantity tango/solver.py:464-475 (check_convergence) forms for one run, taken
+ * over every profile that still iterates: out[0..4] (device doubles, zeroed by the call) = sum of squared normalised
+ * residuals (n x rms^2 of each such profile's latest history entry), number of residual entries behind that sum,
+ * number of profiles still iterating, largest latest rms of any profile, 1 if any profile is invalid.  Entries 0-2
+ * add up over the shards of a distributed ensemble, entries 3-4 take the maximum; sqrt(out[0]/out[1]) is the rms
+ * residual of everything that is still iterating.  err / err_stride / iters are those of tg_state_1f or tg_state_3f. */
+int tg_residual_reduce(const int32_t *status, const int32_t *iters, const double *err, int64_t err_stride, int64_t nb,
+                       int64_t n, double *out, tg_stream stream);
+
 /* ---- fused Picard iteration, three fields n, pi<->pe -------------------------------------------
  * examples/shestakov_threefield_nonlinearnu.py:52-149 on the same call stack: shared D = (dpi/dx)^2/pi^2
  * for the three fluxes, sources S_n = 8[x<.3], S_i = [x<.1], S_e = 3x[x<.4], collisional coupling

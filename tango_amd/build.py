@@ -11,7 +11,8 @@ says otherwise.  Where the rounding of a single operation matters the kernels sa
 sequences and the slack-carrying elimination call __builtin_fma where they need one rounding, and the
 batch-fastest Thomas kernel, which reproduces LAPACK dgtsv operation by operation, switches contraction off for
 its body.  `python tango_amd/build.py --contract-off` builds lib/libtango_hip_nocontract.so with -ffp-contract=off
-for comparison (TANGO_HIP_LIB selects the library a process loads).
+for comparison (TANGO_HIP_LIB selects the library a process loads); measured on MI355X with bench.py, the two
+builds run within 1 % of each other (5227 against 5178 iterations/s at 64 iterations per launch, 2631 against 2628 at one).
 """
 import concurrent.futures
 import os

@@ -538,6 +538,49 @@ __global__ void status_reduce_kernel(const int32_t *__restrict__ status, int64_t
     }
 }
 
+// Residual summary of an ensemble (tango/solver.py:464-475 taken over every profile that still iterates): from each
+// profile's latest rms residual, out[0] = sum over those profiles of sum_j r_j^2 (= n rms^2), out[1] = the number of
+// residual entries behind it (n per profile), out[2] = profiles still iterating, out[3] = the largest latest rms of
+// any profile, out[4] = 1 if any profile is invalid.  out[0..2] add up over shards, out[3..4] take the maximum.
+__global__ void residual_reduce_kernel(const int32_t *__restrict__ status, const int32_t *__restrict__ iters,
+                                       const double *__restrict__ err, int64_t err_stride, int64_t nb, int n, double *out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double ss = 0.0, cnt = 0.0, act = 0.0, mx = 0.0, inv = 0.0;
+    for (; i < nb; i += stride) {
+        const int s = status[i];
+        const int it = iters[i];
+        const bool has = it > 0 && it <= err_stride;
+        const double rms = has ? err[i * err_stride + it - 1] : 0.0;
+        const bool active = (s & (TG_ST_CONVERGED | TG_ST_INVALID)) == 0;
+        if (active && has) {
+            ss += rms * rms * (double)n;
+            cnt += (double)n;
+        }
+        act += active ? 1.0 : 0.0;
+        mx = fmax(mx, rms);          // fmax drops a NaN residual; such a profile is reported through `invalid`
+        inv = fmax(inv, (s & TG_ST_INVALID) ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        ss += __shfl_xor(ss, m, 64);
+        cnt += __shfl_xor(cnt, m, 64);
+        act += __shfl_xor(act, m, 64);
+        mx = fmax(mx, __shfl_xor(mx, m, 64));
+        inv = fmax(inv, __shfl_xor(inv, m, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt != 0.0) {
+            atomicAdd(&out[0], ss);
+            atomicAdd(&out[1], cnt);
+        }
+        if (act != 0.0) atomicAdd(&out[2], act);
+        // non-negative doubles order like their bit patterns
+        if (mx > 0.0) atomicMax(reinterpret_cast<unsigned long long *>(&out[3]), (unsigned long long)__double_as_longlong(mx));
+        if (inv > 0.0) atomicMax(reinterpret_cast<unsigned long long *>(&out[4]), (unsigned long long)__double_as_longlong(inv));
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Fused Picard iteration, one field.
 // ------------------------------------------------------------------------------------------
@@ -1334,6 +1377,16 @@ int tg_status_reduce(const int32_t *status, int64_t nb, int64_t *counts, tg_stre
     if (nb == 0) return TG_OK;
     hipLaunchKernelGGL(status_reduce_kernel, dim3(grid_1d(nb, 256)), dim3(256), 0, S(stream), status, nb,
                        reinterpret_cast<unsigned long long *>(counts));
+    return launch_check();
+}
+
+int tg_residual_reduce(const int32_t *status, const int32_t *iters, const double *err, int64_t err_stride, int64_t nb, int64_t n,
+                       double *out, tg_stream stream) {
+    if (!status || !iters || !err || !out || nb < 0 || n < 1 || err_stride < 1) return fail(TG_ERR_ARG, "bad argument%s");
+    TG_HIP(hipMemsetAsync(out, 0, 5 * sizeof(double), S(stream)));
+    if (nb == 0) return TG_OK;
+    hipLaunchKernelGGL(residual_reduce_kernel, dim3(grid_1d(nb, 256)), dim3(256), 0, S(stream), status, iters, err, err_stride, nb,
+                       (int)n, out);
     return launch_check();
 }
 

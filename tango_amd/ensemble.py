@@ -178,3 +178,74 @@ class OneFieldEnsemble:
         counts_ptr, 4 int64 on the device)."""
         H.check(H.lib.tg_status_reduce(H.ptr_of(self.status), self.nb, counts_ptr or H.ptr_of(self.counts),
                                        stream if stream is not None else H.stream()))
+
+    def reduce_residual(self, out_ptr, stream=None):
+        """Launch the residual summary of tg_residual_reduce into 5 device doubles at out_ptr (needs keep_err)."""
+        if self.err is None:
+            raise ValueError('the residual summary needs the residual history (keep_err=True)')
+        H.check(H.lib.tg_residual_reduce(H.ptr_of(self.status), H.ptr_of(self.iters), H.ptr_of(self.err), self.state.err_stride,
+                                         self.nb, self.n, out_ptr, stream if stream is not None else H.stream()))
+
+
+def pooled(shapes_dtypes, alloc=None):
+    """One skewed pool holding an array for every (shape, dtype) of the list; returns (pool, views)."""
+    pool = Pool(Pool.size_for(shapes_dtypes), alloc)
+    return pool, [pool.take(shape, dtype) for shape, dtype in shapes_dtypes]
+
+
+class ThreeFieldEnsemble:
+    """Device-resident state of a three-field (n, pi, pe) ensemble plus the parameter block of tg_picard_3f_step
+    (the problem of examples/shestakov_threefield_nonlinearnu.py:52-206, one collision amplitude nu0 and one set
+    of right boundary values per profile).  The fifteen state arrays live in one pool with skewed offsets."""
+
+    def __init__(self, ens, dt=1e6, a_turb=0.3, a_prof=0.3, tol=1e-9, theta=THETA_DEFAULT, max_iter=400,
+                 fixed_count=False, keep_err=True, alloc=None):
+        from .extras.threefield import source_e, source_i, source_n
+        u0 = np.ascontiguousarray(ens['u0'], dtype=np.float64)
+        self.nb, self.n = nb, n = u0.shape
+        f8, i4, i8 = np.float64, np.int32, np.int64
+        plan = [((nb, n), f8)] * 15 + [((nb,), i4)] * 2 + [((nb,), f8)] * 4 + [((n,), f8)] * 3 + [((4,), i8)]
+        if keep_err:
+            plan.append(((nb, max_iter), f8))
+        self.pool, v = pooled(plan, alloc)
+        self.u, self.um1, self.uE, self.DE, self.cE = (v[3 * k:3 * k + 3] for k in range(5))
+        self.status, self.iters = v[15], v[16]
+        self.UL, self.nu0, self.H7, self.counts = v[17:20], v[20], v[21:24], v[24]
+        self.err = v[25] if keep_err else None
+        for k in range(3):
+            self.u[k].set(u0)
+            self.um1[k].set(u0)
+            self.UL[k].set(np.ascontiguousarray(ens['bc'][:, k]))
+        for a in self.uE + self.DE + self.cE + [self.status, self.iters, self.counts] + ([self.err] if keep_err else []):
+            a.zero()
+        self.nu0.set(ens['nu0'])
+        for a, src in zip(self.H7, (source_n, source_i, source_e)):
+            a.set(src(np.asarray(ens['x'], dtype=np.float64)))
+        P3 = H._p * 3
+        ptrs = lambda arrs: P3(*[a.ptr for a in arrs])
+        self.state = H.State3F(nb, n, ptrs(self.u), ptrs(self.um1), ptrs(self.uE), ptrs(self.DE), ptrs(self.cE),
+                               self.status.ptr, self.iters.ptr, self.err.ptr if keep_err else None,
+                               max_iter if keep_err else 0)
+        q = H.Params3F()
+        q.dt, q.dx, q.a_turb, q.a_prof = float(dt), float(ens['dx']), float(a_turb), float(a_prof)
+        q.Dmin, q.Dmax, q.dpdx_thr, q.tol = float(theta['Dmin']), float(theta['Dmax']), float(theta['dpdxThreshold']), float(tol)
+        q.UL, q.H7, q.nu0 = ptrs(self.UL), ptrs(self.H7), self.nu0.ptr
+        q.fixed_count, q.frozen_turb, q.outer_count = int(fixed_count), 0, 0
+        self.params = q
+
+    def step(self, stream=None, iters=1):
+        """`iters` Picard iterations of every active profile, one launch each (asynchronous)."""
+        for _ in range(int(iters)):
+            H.check(H.lib.tg_picard_3f_step(C.byref(self.state), C.byref(self.params), stream if stream is not None else H.stream()))
+
+    def reduce_status(self, stream=None, counts_ptr=None):
+        H.check(H.lib.tg_status_reduce(H.ptr_of(self.status), self.nb, counts_ptr or H.ptr_of(self.counts),
+                                       stream if stream is not None else H.stream()))
+
+    def reduce_residual(self, out_ptr, stream=None):
+        """Launch the residual summary of tg_residual_reduce into 5 device doubles at out_ptr (needs keep_err); a
+        profile's rms is taken over the 3 n residual entries of its three fields (tango/solver.py:464-470)."""
+        if self.err is None:
+            raise ValueError('the residual summary needs the residual history (keep_err=True)')
+        H.check(H.lib.tg_residual_reduce(H.ptr_of(self.status), H.ptr_of(self.iters), H.ptr_of(self.err), self.state.err_stride,
+                                         self.nb, 3 * self.n, out_ptr, stream if stream is not None else H.stream()))
