@@ -37,3 +37,19 @@ def relerr(a, b):
     b = np.asarray(b, dtype=float)
     den = np.max(np.abs(b))
     return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
+
+
+def relerr_elem(a, b):
+    """max over elements of |a-b| / |b| (entries with |b| < 1e-300 left out): no slack for the small tail of a profile."""
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    ok = np.abs(b) > 1e-300
+    return float(np.max(np.abs(a - b)[ok] / np.abs(b)[ok])) if ok.any() else 0.0
+
+
+def relerr_tail(a, b):
+    """relerr restricted to the last quarter of the grid (last axis), where a Shestakov profile is ~100 times smaller."""
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    q = b.shape[-1] - b.shape[-1] // 4
+    return relerr(a[..., q:], b[..., q:])

@@ -78,7 +78,8 @@ def test_tridiag_picard_matrices_vs_extended_precision(tango):
         for j in range(n - 2, -1, -1):
             u[j] = dp[j] - cp[j] * u[j + 1]
         return u.astype(float)
-    for N, bar in ((512, 1e-11), (8192, 5e-10)):
+    # measured at N = 8192: 1.4e-10 from LAPACK's solution, which itself lies 1e-10 from the extended-precision one
+    for N, bar in ((512, 1e-11), (8192, 3e-10)):
         dx = 1.0 / (N - 1); x = np.arange(N) * dx
         st = orc.State1F(1 - 0.5 * x)
         for _ in range(6):

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import relerr
+from conftest import relerr, relerr_elem, relerr_tail
 from oracle import tango_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -80,10 +80,13 @@ def test_fused_step_trajectory_vs_reference(tango, golden, N, tag, ap):
             assert relerr(E.DE.to_host()[0], g[f'{key}_it{it}_DE']) < TOL
             assert relerr(E.cE.to_host()[0], g[f'{key}_it{it}_cE']) < TOL
             assert relerr(E.uE.to_host()[0], g[f'{key}_it{it}_uE']) < TOL
+            # element by element and on the small tail of the profile too (measured: <= 6e-12 at N = 512)
+            for got_, ref_ in ((E.u, f'{key}_it{it}_u'), (E.DE, f'{key}_it{it}_DE'), (E.cE, f'{key}_it{it}_cE')):
+                assert relerr_elem(got_.to_host()[0], g[ref_]) < TOL and relerr_tail(got_.to_host()[0], g[ref_]) < TOL
     got = int(E.iters.to_host()[0])
     assert same_stop(got, iters, g[f'{key}_err'], 1e-11)
     assert int(E.status.to_host()[0]) & 1
-    assert relerr(E.u.to_host()[0], g[f'{key}_final']) < TOL
+    assert relerr(E.u.to_host()[0], g[f'{key}_final']) < TOL and relerr_elem(E.u.to_host()[0], g[f'{key}_final']) < TOL
     if got == iters:
         assert relerr(E.DE.to_host()[0], g[f'{key}_last_DE']) < TOL and relerr(E.cE.to_host()[0], g[f'{key}_last_cE']) < TOL
     k = min(got, iters)
@@ -155,8 +158,10 @@ def test_ensemble32_matches_reference(tango, golden):
         k2 = min(got, k)
         assert np.allclose(s.errHistory[b, :k2], g['errs'][b, :k2], rtol=1e-6, atol=2e-12)
         assert np.all(s.errHistory[b, got:] == 0)
-        assert relerr(s.profiles['n'][b], g['finals'][b]) < TOL
-    assert same >= 24      # the great majority stop on the reference's iteration
+        assert relerr(s.profiles['n'][b], g['finals'][b]) < TOL and relerr_elem(s.profiles['n'][b], g['finals'][b]) < TOL
+    # measured: 28 of the 32 stop on the reference's iteration, three one iteration and one two iterations later (all four have
+    # deciding residuals within 25 % of tol, see same_stop); profiles/r02_parity_report.json
+    assert same >= 26
 
 
 def test_example_script_callbacks_take_the_fused_path(tango, golden):
@@ -249,7 +254,8 @@ def test_fused_step_other_sizes_vs_oracle(tango, N):
     for _ in range(its):
         E.step()
     H7 = orc.shestakov_source(ens['x'], ens['S0'], ens['delta'])
-    bar = TOL if N <= 1024 else (3e-10 if N <= 2048 else 1e-9)     # conditioning grows as N^2 (cond ~1e9 at N=2048)
+    # measured after 50 iterations of the example problem (profiles/r02_parity_report.json): 2e-11 at N = 2048, 1.2e-10 at 4096
+    bar = TOL if N <= 2048 else 3e-10
     for b in range(nb):
         st = orc.State1F(ens['u0'][b])
         for _ in range(its):
@@ -259,8 +265,10 @@ def test_fused_step_other_sizes_vs_oracle(tango, N):
 
 
 def test_fine_grid_vs_reference(tango, golden):
-    """N = 8192 (cond ~1e11): LAPACK's own solution is ~1e-10 from the exact solution of its matrix, so the
-    bar here is 2e-9 against the reference (see test_tridiag_picard_matrices_vs_extended_precision)."""
+    """N = 8192 (cond ~1e11), 50 iterations of the reference's trajectory.  Measured (profiles/r02_parity_report.json):
+    the profile agrees with the reference to 7e-11 (1.3e-10 element-wise), D and c to 1.5e-10 and 2.2e-10: D ~ (u'/u)^2
+    amplifies point-to-point rounding noise of u by 2 / (dx u'/u) ~ 3e4 on this grid, so 1e-10 in D would need the two
+    solves to agree to 3e-15.  Bars: 3e-10 for the profile."""
     from tango_amd.ensemble import OneFieldEnsemble
     g = golden('g8_onefield')
     N = 8192; x = np.arange(N) * (1 / (N - 1))
@@ -269,8 +277,8 @@ def test_fine_grid_vs_reference(tango, golden):
     for it in range(50):
         E.step()
         if it in (0, 10):
-            assert relerr(E.u.to_host()[0], g[f'N8192_it{it}_u']) < 2e-9
-    assert relerr(E.u.to_host()[0], g['N8192_final']) < 2e-9
+            assert relerr(E.u.to_host()[0], g[f'N8192_it{it}_u']) < 3e-10
+    assert relerr(E.u.to_host()[0], g['N8192_final']) < 3e-10 and relerr_elem(E.u.to_host()[0], g['N8192_final']) < 5e-10
     assert np.allclose(E.err.to_host()[0], g['N8192_err'], rtol=1e-4)
 
 
@@ -687,7 +695,7 @@ def test_segmented_long_profiles_match_the_workgroup_kernel(tango, N, nb):
         assert np.array_equal(ia, ib) and np.array_equal(A.status.to_host(), B.status.to_host())
         if not fixed:
             assert np.all(ia < total) and np.all(A.status.to_host() & 1)
-        bar = 2e-9          # cond ~1e11 and beyond: two elimination orders agree to about cond x eps
+        bar = 5e-10         # two elimination orders on cond ~1e11 matrices; D and c amplify rounding noise of u by ~1/dx
         for x, y in ((A.u, B.u), (A.uE, B.uE), (A.DE, B.DE), (A.cE, B.cE)):
             assert relerr(y.to_host(), x.to_host()) < bar
         k = int(ia.min())
