@@ -184,7 +184,8 @@ typedef struct {
     const double *gxx_turb, *gradx_turb;   /* optional (n,) geometry used by the flux split */
     const double *flux;  /* (nb,n) flux when flux_model == TG_FLUX_EXTERNAL (profile EWMA already advanced) */
     int32_t flux_model;
-    int32_t smooth_window; /* odd; 1 = no smoothing */
+    int32_t smooth_window; /* centred moving average of the flux before the split (tango/smoother.py:13-48 at
+                              tango/lodestro_method.py:359-362): odd window in points, <= 1 = no smoothing; n <= 4096 */
     int32_t fixed_count;   /* nonzero: step every profile regardless of its status, never mark converged */
     int32_t frozen_turb;   /* nonzero: reuse DE,cE as they are (inner iteration, tango/solver.py:274-309) */
     int32_t iters_per_launch; /* <= 1: one iteration per call; k > 1: up to k iterations per call with the profile
@@ -199,7 +200,7 @@ typedef struct {
     int32_t tread_lightly;
     int32_t tread_inner_count;
     int32_t tread_initial_steps;
-    int32_t reserved_;
+    int32_t reserved_;     /* set to 0; used by the library */
     double tread_max_change;
     double tread_initial_dtau;
     /* Optional work space of tg_picard_1f_work_bytes(nb, n) bytes.  With it, profiles of more than 4096 points

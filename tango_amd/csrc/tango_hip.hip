@@ -581,6 +581,44 @@ __global__ void residual_reduce_kernel(const int32_t *__restrict__ status, const
     }
 }
 
+// Centred moving average of the flux along a profile inside the fused step (tango/smoother.py:13-48 at its call site
+// tango/lodestro_method.py:359-362): full window 2h+1 in the interior, the symmetric window 2j+1 on the h points at
+// either end, each window summed left to right and divided by its length, as moving_average_kernel does.  The P
+// values per lane go through a row in LDS (`row`: the region of this lane group's profile); element e sits in slot
+// e + e/8, one double of padding per lane chunk, so that lanes reading the same window position (a stride of 8
+// elements) fall on different banks.
+template <int P, class G>
+__device__ __forceinline__ void smooth_flux(double *row, int n, int j0, int h, double (&fl)[P]) {
+    auto barrier = [] {
+        if constexpr (G::kBlock) {
+            __syncthreads();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int e = j0 + i;
+        row[e + (e >> 3)] = fl[i];
+    }
+    barrier();
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int j = j0 + i;
+        if (j < n) {
+            int hh = h;
+            hh = j < hh ? j : hh;
+            hh = (n - 1 - j) < hh ? (n - 1 - j) : hh;
+            double sum = 0.0;
+            for (int k = j - hh; k <= j + hh; ++k) sum += row[k + (k >> 3)];
+            fl[i] = sum / (double)(2 * hh + 1);
+        }
+    }
+    barrier();
+}
+
 // ------------------------------------------------------------------------------------------
 // Fused Picard iteration, one field.
 // ------------------------------------------------------------------------------------------
@@ -831,6 +869,29 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             }
             const double wl = g.from_left(ue[P - 1], 1, 0.0);
             const double wr = g.from_right(ue[0], 1, 0.0);
+            // Flux smoothing (tango/lodestro_method.py:359-362): the flux of the whole profile has to exist before any point
+            // is split, so the built-in model is evaluated into fl first; from there on it is treated like an outside flux.
+            bool have_flux = external;
+            if constexpr (GENERAL) {
+                if (Q.smooth_window > 1) {
+                    if (!external) {
+#pragma unroll
+                        for (int i = 0; i < P; ++i) {
+                            const int j = j0 + i;
+                            const bool first = (i == 0) && lane_first;
+                            const bool last = FULL ? (i == P - 1 && t == G::T - 1) : (j == n - 1);
+                            const double pm = (i == 0) ? wl : ue[i > 0 ? i - 1 : 0];
+                            const double pp = (i == P - 1) ? wr : ue[i < P - 1 ? i + 1 : 0];
+                            const double dpdx = ddx_edge1_point<EXACT>(pm, ue[i], pp, first, last, rc);
+                            fl[i] = quot<DIV>(-(dpdx * dpdx * dpdx), ue[i] * ue[i]);
+                        }
+                    }
+                    double *row = lds + Q.reserved_;
+                    if constexpr (!G::kBlock) row += (threadIdx.x >> 6) * 576 + ((threadIdx.x & 63) / G::T) * (G::T * 9);
+                    smooth_flux<P, G>(row, n, j0, (Q.smooth_window - 1) / 2, fl);
+                    have_flux = true;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 const int j = j0 + i;
@@ -847,7 +908,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                     double flux = quot<DIV>(-(dpdx * dpdx * dpdx), p * p);
                     double gx = 1.0, gr = 1.0;
                     if constexpr (GENERAL) {
-                        flux = external ? fl[i] : flux;
+                        flux = have_flux ? fl[i] : flux;
                         gx = Q.gxx_turb ? gxt[i] : 1.0;
                         gr = Q.gradx_turb ? grt[i] : 1.0;
                     }
@@ -1140,9 +1201,20 @@ struct Picard1fLauncher {
                        reinterpret_cast<uintptr_t>(q->gradx) | reinterpret_cast<uintptr_t>(q->gxx_turb) |
                        reinterpret_cast<uintptr_t>(q->gradx_turb) | reinterpret_cast<uintptr_t>(q->iterates);
         const bool full = (n == P * G::T) && (al & 15) == 0;
-        const bool general = q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly;
+        const bool general = q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly ||
+                             q->smooth_window > 1;
         const bool multi = q->iters_per_launch > 1;
         if (kWaveCoop<P, G, true> && full) lds += (size_t)(block / 64) * kCoopTiles<G> * WaveTile<8>::kDoubles * sizeof(double);
+        tg_params_1f qs = *q;
+        qs.reserved_ = 0;
+        if (q->smooth_window > 1) {
+            // one padded row per profile for the flux smoothing, behind the exchange area and the tiles
+            if (n > 4096) return fail(TG_ERR_UNSUPPORTED, "flux smoothing inside the fused step needs n <= 4096%s");
+            qs.reserved_ = (int32_t)(lds / sizeof(double));
+            lds += sizeof(double) * (G::kBlock ? (size_t)G::T * P * 9 / 8 + 8 : (size_t)(block / 64) * 576);
+            if (lds > max_lds_bytes()) return fail(TG_ERR_UNSUPPORTED, "flux smoothing: not enough LDS for this grid size%s");
+        }
+        q = &qs;
 #define TG_LAUNCH_1F(F, GEN, M) hipLaunchKernelGGL((picard_1f_kernel<P, G, F, GEN, M>), dim3(grid), dim3(block), lds, s, *st, *q)
         if (general && multi) {
             if (full) TG_LAUNCH_1F(true, true, true);
@@ -1179,7 +1251,8 @@ int tg_picard_1f_validate(const tg_state_1f *st, const tg_params_1f *q) {
         return fail(TG_ERR_ARG, "tread_lightly needs 0 <= tread_inner_count <= n and tread_max_change > 0%s");
     if (q->tread_initial_steps < 0 || (q->tread_initial_steps > 0 && (!q->pseudo_time || !(q->tread_initial_dtau > 0.0))))
         return fail(TG_ERR_ARG, "tread_initial_steps needs pseudo_time and tread_initial_dtau > 0%s");
-    if (q->smooth_window > 1) return fail(TG_ERR_UNSUPPORTED, "flux smoothing is not fused; smooth the flux with tg_moving_average and pass it as an external flux%s");
+    if (q->smooth_window > 1 && (q->smooth_window % 2 == 0 || q->smooth_window > st->n))
+        return fail(TG_ERR_ARG, "smooth_window must be odd and no larger than the grid (callers add one to an even window, tango/smoother.py:50-57)%s");
     if (st->err && st->err_stride <= 0) return fail(TG_ERR_ARG, "err_stride must be positive%s");
     if (q->iterates && q->iterates_rows < 0) return fail(TG_ERR_ARG, "iterates_rows must not be negative%s");
     return TG_OK;

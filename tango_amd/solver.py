@@ -26,6 +26,7 @@ from . import _hip as H
 from . import fieldgroups, tango_logging
 from . import multifield as _mf
 from . import lodestro_method as _lm
+from . import smoother as _smoother
 
 
 def duration_as_hms(seconds):
@@ -407,8 +408,12 @@ def _plan_fused(s):
         return not (np.ndim(sp.gxxAvg) or np.ndim(sp.gradxAvg) or sp.gxxAvg != 1 or sp.gradxAvg != 1)
 
     model = getattr(th.fluxModel, 'fused_flux_model', None)
+    n_points = np.shape(s.x)[-1]
+    # the packaged moving average runs inside the fused kernel (grids of up to 4096 points); any other smoother on the host
+    fused_smoothing = th.doSmoothing and type(th.fluxSmoother) is _smoother.Smoother and n_points <= 4096 \
+        and th.fluxSmoother.windowSize <= n_points
     one = len(s.fields) == 1 and s.fields[0].coupledTo is None and not s.useInnerIteration and th.dxTurbGrid == s.dx
-    if one and model == 'shestakov' and not th.doSmoothing and not th.isNonCartesian and plain(s.fields[0].lodestroMethod._fluxSplitter) \
+    if one and model == 'shestakov' and (not th.doSmoothing or fused_smoothing) and not th.isNonCartesian and plain(s.fields[0].lodestroMethod._fluxSplitter) \
             and getattr(s.fields[0].compute_all_H, 'fused_source', None) is not None and th.fluxModel.dx == s.dx:
         return _Fused1F(s)
     if one and _callback_is_static(s):
@@ -500,7 +505,7 @@ class _Fused1F(object):
         q.UL, q.S0, q.src_cut = self.UL.ptr, ptr(self.S0), ptr(self.src_cut)
         if getattr(self, 'work', None) is not None:
             q.work, q.work_bytes = self.work.ptr, self.work.nbytes
-        q.flux_model, q.smooth_window, q.fixed_count, q.frozen_turb = H.FLUX_SHESTAKOV, 1, 0, 0
+        q.flux_model, q.smooth_window, q.fixed_count, q.frozen_turb = H.FLUX_SHESTAKOV, self._smooth_window(s), 0, 0
         # pseudo-timestep control (tango/solver.py:198-216, 311-372) runs inside the kernel
         q.pseudo_time = int(bool(s.useTreadLightly or s.useTreadInitially))
         if s.useTreadLightly:
@@ -511,6 +516,15 @@ class _Fused1F(object):
             q.tread_initial_steps = int(s.treadInitiallyParams['numInitialSteps'])
             q.tread_initial_dtau = float(s.treadInitiallyParams['dtau'])
         return q
+
+    @staticmethod
+    def _smooth_window(s):
+        """Window of the packaged flux smoother when the kernel does the smoothing (tango/lodestro_method.py:359-362), else 1."""
+        th = s.compute_all_H_all_fields.turbhandler
+        if th.doSmoothing and type(th.fluxSmoother) is _smoother.Smoother and np.shape(s.x)[-1] <= 4096 \
+                and th.fluxSmoother.windowSize <= np.shape(s.x)[-1]:
+            return int(th.fluxSmoother.windowSize)
+        return 1
 
     def run_timestep(self, s):
         q = self.params(s)
@@ -677,7 +691,8 @@ class _FusedExternal1F(_Fused1F):
             H.check(H.lib.tg_memset(self.err.ptr, 0, self.err.nbytes, H.stream()))
         done = self.start = s.iterationNumber
         hist = s.profilesAllIterations
-        if getattr(th.fluxModel, 'device_flux', False) and not th.doSmoothing:
+        host_smoothing = th.doSmoothing and q.smooth_window <= 1       # a smoother the kernel does not implement
+        if getattr(th.fluxModel, 'device_flux', False) and not host_smoothing:
             return self._run_timestep_device_flux(s, q, th, a_prof)
         pick = (lambda a: a) if s.batched else (lambda a: a[0])
         u = self.u.to_host()
@@ -692,7 +707,7 @@ class _FusedExternal1F(_Fused1F):
             new = a_prof * u + (1 - a_prof) * self.uE_host
             self.uE_host[active] = new[active]
             flux = np.asarray(th.fluxModel.get_flux({self.label: pick(self.uE_host)})[self.label], dtype=np.float64)
-            if th.doSmoothing:
+            if host_smoothing:
                 flux = np.asarray(th.fluxSmoother.smooth(flux), dtype=np.float64)
             self.uE.set(self.uE_host)
             self.flux.set(np.atleast_2d(flux))

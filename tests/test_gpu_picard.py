@@ -626,6 +626,11 @@ def test_python_flux_model_in_noncartesian_geometry(tango, golden, tag, fused):
     s = tango.solver.Solver(1, x, np.array([0, 50.0]), 40 if sm else 600, 1e-10, tango.multifield.ComputeAllHAllFields([f], turb), [f],
                             detectStaticH=fused)
     assert (s._fused is not None) == fused
+    if fused and tag == 'smooth':       # the moving average runs inside the fused kernel: the host-side smoother must stay idle
+        def idle(flux):
+            raise AssertionError('flux smoothed on the host')
+        turb.fluxSmoother.smooth = idle
+        assert s._fused._smooth_window(s) == 7
     while s.ok:
         s.take_timestep()
     k = int(g[f'{tag}_iters'])
@@ -676,6 +681,36 @@ def test_python_flux_model_ensemble(tango, golden):
             assert relerr(s.profiles['n'][b], st.u) < TOL, b
             assert relerr(lm._EWMAProfile._yEWMA_lminus1[b], st.uE) < TOL, b
     assert len(set(its)) > 1
+
+
+@pytest.mark.parametrize('N,nb,window,k', [(512, 5, 11, 1), (512, 3, 5, 4), (256, 7, 3, 1), (64, 9, 21, 1), (500, 3, 11, 1), (100, 4, 7, 3),
+                                            (1000, 2, 21, 1), (2048, 2, 41, 1), (4096, 1, 11, 1)])
+def test_flux_smoothing_inside_the_fused_step(tango, N, nb, window, k):
+    """The moving average of the flux (tango/smoother.py:13-48 at tango/lodestro_method.py:359-362) computed by the fused
+    kernel itself, built-in flux model, against the CPU oracle: full and ragged grids, short profiles sharing a wavefront,
+    workgroup-per-profile grids, windows reaching across several lanes, one and several iterations per launch."""
+    from tango_amd.ensemble import OneFieldEnsemble
+    its = 6
+    ens = orc.shestakov_ensemble(nb, N)
+    E = OneFieldEnsemble(ens, a_prof=0.3, max_iter=its + 2, fixed_count=True, segmented=False)
+    E.params.smooth_window = window
+    done = 0
+    while done < its:
+        E.step(iters=min(k, its - done))
+        done += min(k, its - done)
+    H7 = orc.shestakov_source(ens['x'], ens['S0'], ens['delta'])
+    u, DE, cE, err = E.u.to_host(), E.DE.to_host(), E.cE.to_host(), E.err.to_host()
+    for b in range(nb):
+        st = orc.State1F(ens['u0'][b])
+        for it in range(its):
+            rms, bad = orc.picard_step_1f(st, 1e4, ens['dx'], ens['nL'][b], np.ones(N), H7[b], 0.3, 0.3, smooth_window=window)
+            assert abs(err[b, it] - rms) <= 1e-6 * rms + 2e-12
+        bar = TOL if N <= 2048 else 3e-10
+        assert relerr(u[b], st.u) < bar and relerr(DE[b], st.DE) < bar and relerr(cE[b], st.cE) < bar, (b, relerr(DE[b], st.DE))
+    # an even window, or one wider than the grid, is refused
+    E.params.smooth_window = 4
+    with pytest.raises(ValueError):
+        E.step()
 
 
 @pytest.mark.parametrize('N,nb', [(8192, 3), (16384, 2)])
