@@ -129,6 +129,21 @@ size_t tg_spline_work_bytes(int64_t nb, int64_t nin);
 int tg_spline_resample(const double *xin, const double *yin, int64_t nb, int64_t nin, const double *xout, int64_t nout,
                        int64_t out_lo, int64_t out_hi, int nonneg, double *yout, void *work, size_t work_bytes,
                        tg_stream stream);
+/* Symmetric Tukey (tapered cosine) window of n points with cosine fraction alpha, the taper scipy.signal.tukey gives
+ * tango/extras/bufferzone.py:51: w (n,) device array. */
+int tg_tukey_window(double *w, int64_t n, double alpha, tg_stream stream);
+
+/* Multiplicative flux noise of tango/extras/noisyflux.py:43-62,106-162 generated on the device:
+ * out[b][j] = (1 + d_j amplitude y_bj) * (taper ? taper[j] : 1), y_b a unit-variance AR(1) series along the grid with
+ * lag-one correlation (tac-1)/(tac+1) (tac = correlation length in grid points, > 1), d the linear ramp of
+ * dampen_sides (0 at both ends, 1 after damp_points points).  The white noise comes from a counter-based generator
+ * (Philox 4x32-10, Box-Muller) keyed by (seed, sequence, profile, point): the same arguments give the same numbers on
+ * any launch shape; use a new sequence number for every Picard iteration.  The series starts in its stationary
+ * distribution (the reference reaches it by discarding a burn-in).  The reference draws from NumPy's global Mersenne
+ * Twister, which no device generator reproduces: statistically equivalent noise, not the same numbers. */
+int tg_ar1_noise(uint64_t seed, uint64_t sequence, double amplitude, double tac, int32_t damp_points, const double *taper,
+                 double *out, int64_t nb, int64_t n, tg_stream stream);
+
 /* Gamma = -(dn/dx)^3 / n^2 */
 int tg_shestakov_flux(const double *nprof, double dx, double *flux, int64_t nb, int64_t n,
                       tg_stream stream);
@@ -166,7 +181,10 @@ typedef struct {
     int64_t err_stride;
 } tg_state_1f;
 
-enum { TG_FLUX_SHESTAKOV = 0, TG_FLUX_EXTERNAL = 1 };
+/* TG_FLUX_SHESTAKOV: Gamma = -(dp/dx)^3 / p^2 (tango/extras/shestakov_nonlinear_diffusion.py:51-61).
+ * TG_FLUX_EXTERNAL: the flux array of tg_params_1f.flux.  TG_FLUX_POWER: Gamma = -|(dp/dx)/p|^q dp/dx with q =
+ * tg_params_1f.flux_power (the FluxModel of examples/stripped_down_tango_example.py:55-65; q = 2 is the Shestakov model). */
+enum { TG_FLUX_SHESTAKOV = 0, TG_FLUX_EXTERNAL = 1, TG_FLUX_POWER = 2 };
 
 typedef struct {
     double dt, dx;
@@ -216,6 +234,13 @@ typedef struct {
      * not used while it is set. */
     double *iterates;
     int64_t iterates_rows;
+    /* Optional multiplier of the flux, applied before smoothing and the split: flux_j *= flux_mult[b*flux_mult_stride + j]
+     * (stride 0: one (n,) array for all profiles, n: an (nb, n) array).  This is where the flux-model decorators of
+     * tango/extras/bufferzone.py:39-54 (a Tukey taper, tg_tukey_window) and tango/extras/noisyflux.py:43-62 (1 + noise,
+     * tg_ar1_noise) act when the flux model is built in; n <= 4096. */
+    const double *flux_mult;
+    int64_t flux_mult_stride;
+    double flux_power;     /* exponent q of TG_FLUX_POWER */
 } tg_params_1f;
 
 enum { TG_TREAD_MAX_HALVINGS = 64 };

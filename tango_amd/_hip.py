@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('TANGO_HIP_LIB') or os.path.join(_HERE, 'lib', 'libtan
 TG_OK, TG_ERR_ARG, TG_ERR_HIP, TG_ERR_UNSUPPORTED = 0, 1, 2, 3
 POINT_FASTEST, BATCH_FASTEST = 0, 1
 ST_CONVERGED, ST_INVALID, ST_SINGULAR, ST_SEEDED, ST_TREAD_LIMIT = 1, 2, 4, 8, 16
-FLUX_SHESTAKOV, FLUX_EXTERNAL = 0, 1
+FLUX_SHESTAKOV, FLUX_EXTERNAL, FLUX_POWER = 0, 1, 2
 STATIC_WORK_BYTES = 36 * 1024 * 1024
 
 
@@ -56,7 +56,7 @@ class Params1F(C.Structure):
                 ('iters_per_launch', C.c_int32), ('pseudo_time', C.c_int32), ('tread_lightly', C.c_int32),
                 ('tread_inner_count', C.c_int32), ('tread_initial_steps', C.c_int32), ('reserved_', C.c_int32),
                 ('tread_max_change', _dbl), ('tread_initial_dtau', _dbl), ('work', _p), ('work_bytes', _sz),
-                ('iterates', _p), ('iterates_rows', _i64)]
+                ('iterates', _p), ('iterates_rows', _i64), ('flux_mult', _p), ('flux_mult_stride', _i64), ('flux_power', _dbl)]
 
 
 class State3F(C.Structure):
@@ -98,6 +98,8 @@ PROTOTYPES = {
     'tg_flux_split': (_int, [_p, _p, _dbl, _dbl, _dbl, _dbl, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     'tg_ddx': (_int, [_p, _dbl, _int, _p, _i64, _i64, _p]),
     'tg_moving_average': (_int, [_p, _int, _p, _i64, _i64, _p]),
+    'tg_tukey_window': (_int, [_p, _i64, _dbl, _p]),
+    'tg_ar1_noise': (_int, [C.c_uint64, C.c_uint64, _dbl, _dbl, C.c_int32, _p, _p, _i64, _i64, _p]),
     'tg_shestakov_flux': (_int, [_p, _dbl, _p, _i64, _i64, _p]),
     'tg_pair_solve': (_int, [_p] * 12 + [_i64, _i64, _p, _p]),
     'tg_block3_solve': (_int, [_p, _p, _p, _p, _p, _i64, _i64, _p, _p]),

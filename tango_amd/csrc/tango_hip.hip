@@ -512,6 +512,117 @@ __global__ void spline_eval_kernel(const double *__restrict__ x, const double *_
     }
 }
 
+// Tukey window (tango/extras/bufferzone.py:51 -> scipy.signal.tukey): cosine lobes over the first and last
+// floor(alpha (n-1) / 2) + 1 points, one in between.
+__global__ void tukey_window_kernel(double *__restrict__ w, int n, double alpha) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double v = 1.0;
+    if (n > 1 && alpha > 0.0) {
+        const double a = alpha < 1.0 ? alpha : 1.0;
+        const int width = (int)floor(a * (n - 1) / 2.0);
+        if (k <= width) v = 0.5 * (1.0 + cos(M_PI * (-1.0 + 2.0 * k / a / (n - 1))));
+        if (k >= n - width - 1) v = 0.5 * (1.0 + cos(M_PI * (-2.0 / a + 1.0 + 2.0 * k / a / (n - 1))));
+    }
+    w[k] = v;
+}
+
+// Philox 4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): a keyed bijection of a 128-bit counter.
+struct Philox {
+    uint32_t k0, k1;
+    __device__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+    __device__ void operator()(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) const {
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ b, n3 = (uint32_t)p0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            a += 0x9E3779B9u;
+            b += 0xBB67AE85u;
+        }
+        out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    }
+};
+
+// two independent standard normal numbers for (sequence, profile, pair index): 53-bit uniforms, Box-Muller
+__device__ __forceinline__ void normal_pair(const Philox &rng, uint64_t sequence, uint64_t profile, uint32_t pair, double &z0, double &z1) {
+    uint32_t r[4];
+    rng((uint32_t)sequence ^ (uint32_t)(profile >> 32) * 0x85EBCA6Bu, (uint32_t)(sequence >> 32), (uint32_t)profile, pair, r);
+    const double u0 = ((double)(((uint64_t)r[0] << 21) ^ (r[1] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);     // (0, 1)
+    const double u1 = ((double)(((uint64_t)r[2] << 21) ^ (r[3] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
+    const double rad = sqrt(-2.0 * log(u0));
+    z0 = rad * cos(2.0 * M_PI * u1);
+    z1 = rad * sin(2.0 * M_PI * u1);
+}
+
+// AR(1) flux noise: one wavefront per profile, 512 points per pass (8 per lane).  Every lane runs the recursion
+// y_j = lambda y_{j-1} + a_j over its own points from zero; what the points before it contribute follows from a scan
+// over the lanes of the affine maps c -> lambda^8 c + (lane's last value), and the pass hands its last value on.
+__global__ void __launch_bounds__(256)
+ar1_noise_kernel(uint64_t seed, uint64_t sequence, double amplitude, double lambda, int damp, const double *__restrict__ taper,
+                 double *__restrict__ out, int64_t nb, int n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= nb) return;
+    const Philox rng(seed);
+    const double sd = sqrt(1.0 - lambda * lambda);
+    double lp[9];                       // lambda^0 .. lambda^8
+    lp[0] = 1.0;
+#pragma unroll
+    for (int i = 1; i <= 8; ++i) lp[i] = lp[i - 1] * lambda;
+    // stationary start: the value "before the first point" has unit variance
+    double carry, spare;
+    normal_pair(rng, sequence, (uint64_t)b, 0xFFFFFFFFu, carry, spare);
+    for (int base = 0; base < n; base += 512) {
+        const int j0 = base + lane * 8;
+        double y[8];
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            double z0, z1;
+            normal_pair(rng, sequence, (uint64_t)b, (uint32_t)((j0 + i) >> 1), z0, z1);
+            acc = lambda * acc + sd * z0;
+            y[i] = acc;
+            acc = lambda * acc + sd * z1;
+            y[i + 1] = acc;
+        }
+        // inclusive scan over lanes of (A, B): value after this lane's points = A * (value before lane 0) + B
+        double A = lp[8], B = acc;
+#pragma unroll
+        for (int h = 1; h < 64; h <<= 1) {
+            const double Al = __shfl_up(A, (unsigned)h, 64), Bl = __shfl_up(B, (unsigned)h, 64);
+            if (lane >= h) {
+                B = A * Bl + B;
+                A = A * Al;
+            }
+        }
+        // value before this lane's first point
+        const double Ap = __shfl_up(A, 1u, 64), Bp = __shfl_up(B, 1u, 64);
+        const double before = (lane == 0) ? carry : Ap * carry + Bp;
+        const double lastA = __shfl(A, 63, 64), lastB = __shfl(B, 63, 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = j0 + i;
+            if (j < n) {
+                const double v = y[i] + lp[i + 1] * before;
+                // dampen_sides (tango/extras/noisyflux.py:141-162): np.linspace(0, 1, damp) over the first and last damp points
+                double d = 1.0;
+                if (damp > 1) {
+                    if (j < damp) d = (double)j / (double)(damp - 1);
+                    if (j >= n - damp) d = (double)(n - 1 - j) / (double)(damp - 1);
+                } else if (damp == 1) {
+                    if (j == 0) d = 0.0;
+                    if (j == n - 1) d = 1.0;
+                }
+                const double m = 1.0 + d * (amplitude * v);
+                out[b * (int64_t)n + j] = taper ? m * taper[j] : m;
+            }
+        }
+        carry = lastA * carry + lastB;
+    }
+}
+
 __global__ void status_reduce_kernel(const int32_t *__restrict__ status, int64_t nb, unsigned long long *counts) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -873,7 +984,8 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             // is split, so the built-in model is evaluated into fl first; from there on it is treated like an outside flux.
             bool have_flux = external;
             if constexpr (GENERAL) {
-                if (Q.smooth_window > 1) {
+                const bool power = Q.flux_model == TG_FLUX_POWER;
+                if (Q.smooth_window > 1 || Q.flux_mult || power) {
                     if (!external) {
 #pragma unroll
                         for (int i = 0; i < P; ++i) {
@@ -883,12 +995,23 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                             const double pm = (i == 0) ? wl : ue[i > 0 ? i - 1 : 0];
                             const double pp = (i == P - 1) ? wr : ue[i < P - 1 ? i + 1 : 0];
                             const double dpdx = ddx_edge1_point<EXACT>(pm, ue[i], pp, first, last, rc);
-                            fl[i] = quot<DIV>(-(dpdx * dpdx * dpdx), ue[i] * ue[i]);
+                            // examples/stripped_down_tango_example.py:60-64: Deff = |(dn/dx / n)^q|, Gamma = -Deff dn/dx
+                            fl[i] = power ? -(pow(fabs(dpdx / ue[i]), Q.flux_power) * dpdx) : quot<DIV>(-(dpdx * dpdx * dpdx), ue[i] * ue[i]);
                         }
                     }
-                    double *row = lds + Q.reserved_;
-                    if constexpr (!G::kBlock) row += (threadIdx.x >> 6) * 576 + ((threadIdx.x & 63) / G::T) * (G::T * 9);
-                    smooth_flux<P, G>(row, n, j0, (Q.smooth_window - 1) / 2, fl);
+                    if (Q.flux_mult) {      // flux-model decorators (taper, noise) act on the flux the model returns
+#pragma unroll
+                        for (int i = 0; i < P; ++i) {
+                            const int j = j0 + i;
+                            const int jc = (FULL || j < n) ? j : n - 1;
+                            fl[i] = fl[i] * Q.flux_mult[b * Q.flux_mult_stride + jc];
+                        }
+                    }
+                    if (Q.smooth_window > 1) {
+                        double *row = lds + Q.reserved_;
+                        if constexpr (!G::kBlock) row += (threadIdx.x >> 6) * 576 + ((threadIdx.x & 63) / G::T) * (G::T * 9);
+                        smooth_flux<P, G>(row, n, j0, (Q.smooth_window - 1) / 2, fl);
+                    }
                     have_flux = true;
                 }
             }
@@ -1202,7 +1325,7 @@ struct Picard1fLauncher {
                        reinterpret_cast<uintptr_t>(q->gradx_turb) | reinterpret_cast<uintptr_t>(q->iterates);
         const bool full = (n == P * G::T) && (al & 15) == 0;
         const bool general = q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly ||
-                             q->smooth_window > 1;
+                             q->smooth_window > 1 || q->flux_mult;
         const bool multi = q->iters_per_launch > 1;
         if (kWaveCoop<P, G, true> && full) lds += (size_t)(block / 64) * kCoopTiles<G> * WaveTile<8>::kDoubles * sizeof(double);
         tg_params_1f qs = *q;
@@ -1244,7 +1367,13 @@ int tg_picard_1f_validate(const tg_state_1f *st, const tg_params_1f *q) {
     if (!q->UL) return fail(TG_ERR_ARG, "UL is required%s");
     if (!q->H7 && (!q->S0 || !q->src_cut)) return fail(TG_ERR_ARG, "either H7 or (S0, src_cut) is required%s");
     if (q->flux_model == TG_FLUX_EXTERNAL && !q->flux) return fail(TG_ERR_ARG, "external flux model needs a flux array%s");
-    if (q->flux_model != TG_FLUX_EXTERNAL && q->flux_model != TG_FLUX_SHESTAKOV) return fail(TG_ERR_ARG, "unknown flux model%s");
+    if (q->flux_model != TG_FLUX_EXTERNAL && q->flux_model != TG_FLUX_SHESTAKOV && q->flux_model != TG_FLUX_POWER)
+        return fail(TG_ERR_ARG, "unknown flux model%s");
+    if (q->flux_model == TG_FLUX_POWER && !(q->flux_power >= 0.0)) return fail(TG_ERR_ARG, "TG_FLUX_POWER needs flux_power >= 0%s");
+    if (q->flux_mult && q->flux_mult_stride != 0 && q->flux_mult_stride != st->n)
+        return fail(TG_ERR_ARG, "flux_mult_stride must be 0 (one array for all profiles) or n%s");
+    if ((q->flux_mult || q->flux_model == TG_FLUX_POWER) && st->n > 4096)
+        return fail(TG_ERR_UNSUPPORTED, "a flux multiplier or the power-law flux inside the fused step needs n <= 4096%s");
     if (q->flux_model == TG_FLUX_EXTERNAL && q->iters_per_launch > 1) return fail(TG_ERR_ARG, "an external flux is valid for one iteration only%s");
     if (q->tread_lightly && !q->pseudo_time) return fail(TG_ERR_ARG, "tread_lightly needs pseudo_time (the previous iterate in the u_{m-1} slot)%s");
     if (q->tread_lightly && (q->tread_inner_count < 0 || q->tread_inner_count > st->n || !(q->tread_max_change > 0.0)))
@@ -1408,6 +1537,26 @@ int tg_spline_resample(const double *xin, const double *yin, int64_t nb, int64_t
         return e;
     hipLaunchKernelGGL(spline_eval_kernel, dim3(grid_1d(nb * nout, 256)), dim3(256), 0, S(stream), xin, yin, (const double *)M, nb,
                        (int)nin, xout, (int)nout, (int)out_lo, (int)out_hi, nonneg, yout);
+    return launch_check();
+}
+
+int tg_tukey_window(double *w, int64_t n, double alpha, tg_stream stream) {
+    if (!w || n < 0 || n > INT32_MAX) return fail(TG_ERR_ARG, "bad argument%s");
+    if (n == 0) return TG_OK;
+    hipLaunchKernelGGL(tukey_window_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), w, (int)n, alpha);
+    return launch_check();
+}
+
+int tg_ar1_noise(uint64_t seed, uint64_t sequence, double amplitude, double tac, int32_t damp_points, const double *taper, double *out,
+                 int64_t nb, int64_t n, tg_stream stream) {
+    if (int e = check_dims(nb, n, 1)) return e;
+    if (!out) return fail(TG_ERR_ARG, "NULL array%s");
+    if (!(tac > 1.0)) return fail(TG_ERR_ARG, "the correlation length must exceed one grid point%s");
+    if (damp_points < 0 || 2 * (int64_t)damp_points >= n) return fail(TG_ERR_ARG, "damp_points is too large (tango/extras/noisyflux.py:156)%s");
+    if (nb == 0) return TG_OK;
+    const double lambda = (tac - 1.0) / (tac + 1.0);
+    hipLaunchKernelGGL(ar1_noise_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, S(stream), seed, sequence, amplitude, lambda,
+                       (int)damp_points, taper, out, nb, (int)n);
     return launch_check();
 }
 

@@ -424,7 +424,7 @@ size_t tg_seg_work_bytes(int64_t nb, int64_t n) {
 bool tg_seg_applies(const tg_state_1f *st, const tg_params_1f *q) {
     if (!q->work || tg_seg_work_bytes(st->nb, st->n) == 0 || q->work_bytes < tg_seg_work_bytes(st->nb, st->n)) return false;
     if (q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly ||
-        q->iters_per_launch > 1 || q->smooth_window > 1 || q->iterates)
+        q->iters_per_launch > 1 || q->smooth_window > 1 || q->iterates || q->flux_mult)
         return false;
     uintptr_t al = reinterpret_cast<uintptr_t>(st->u) | reinterpret_cast<uintptr_t>(st->um1) | reinterpret_cast<uintptr_t>(st->uE) |
                    reinterpret_cast<uintptr_t>(st->DE) | reinterpret_cast<uintptr_t>(st->cE) | reinterpret_cast<uintptr_t>(q->work);

@@ -7,13 +7,48 @@ import numpy as np
 
 
 class NoisyFlux(object):
-    def __init__(self, fluxModel, amplitude, tac_x, dx):
+    """device_seed=None (default): the noise is drawn on the host from numpy's global generator, in the reference's
+    order.  device_seed=<int>: the noise is generated on the GPU (tg_ar1_noise: counter-based generator keyed by the
+    seed, the call number, the profile and the grid point; statistically the same process, not the reference's numbers);
+    with a flux model that is built into the fused Picard kernel solver.Solver then keeps the whole iteration on the
+    device, the noise entering as the kernel's flux multiplier."""
+    flux_decorator = 'noise'
+
+    def __init__(self, fluxModel, amplitude, tac_x, dx, device_seed=None):
         self.fluxModel = fluxModel
         self.amplitude = amplitude
         self.tac = tac_x / dx        # correlation length in grid points
+        self.device_seed = device_seed
+        self.calls = 0               # sequence number of the next device draw
+
+    @property
+    def device_flux(self):
+        return self.device_seed is not None and getattr(self.fluxModel, 'device_flux', False)
+
+    def device_multiplier(self, nb, n, out=None, taper=None):
+        """(nb, n) device array of 1 + noise (times an optional (n,) device taper) for the next call."""
+        from .. import _hip as H
+        out = out if out is not None else H.DeviceArray((nb, n))
+        H.check(H.lib.tg_ar1_noise(int(self.device_seed), self.calls, float(self.amplitude), float(self.tac), int(0.03 * n),
+                                   H.ptr_of(taper), H.ptr_of(out), nb, n, H.stream()))
+        self.calls += 1
+        return out
 
     def get_flux(self, profiles):
         fluxes = self.fluxModel.get_flux(profiles)
+        if self.device_seed is not None:
+            out = {}
+            for label, v in fluxes.items():
+                if hasattr(v, 'is_cuda') and v.is_cuda:
+                    import torch
+                    v2 = v.reshape(-1, v.shape[-1])
+                    m = torch.as_tensor(self.device_multiplier(v2.shape[0], v2.shape[1]), device=v.device)
+                    out[label] = (v2 * m).reshape(v.shape)
+                else:
+                    v = np.asarray(v, dtype=np.float64)
+                    v2 = np.atleast_2d(v)
+                    out[label] = (v2 * self.device_multiplier(v2.shape[0], v2.shape[1]).to_host()).reshape(v.shape)
+            return out
         return {label: self._add_noise(fluxes[label], self.amplitude, self.tac) for label in fluxes}
 
     @staticmethod

@@ -21,6 +21,21 @@ class AnalyticFluxModel(object):
         return {'n': get_flux(profiles['n'], self.dx)}
 
 
+class PowerLawFluxModel(object):
+    """Gamma = -|(dn/dx)/n|^p dn/dx, the FluxModel of examples/stripped_down_tango_example.py:55-65 (p = 2 is the
+    Shestakov flux).  Built into the fused Picard kernel (TG_FLUX_POWER); get_flux is the host-array form."""
+    fused_flux_model = 'power'
+
+    def __init__(self, dx, p=2):
+        self.dx = dx
+        self.p = p
+
+    def get_flux(self, profiles):
+        n = np.asarray(profiles['n'], dtype=float)
+        dndx = _ops.ddx(n, self.dx, 1)
+        return {'n': -np.abs((dndx / n) ** self.p) * dndx}
+
+
 def H7contrib_Source(x):
     return GetSource(x)
 

@@ -407,15 +407,22 @@ def _plan_fused(s):
     def plain(sp):
         return not (np.ndim(sp.gxxAvg) or np.ndim(sp.gradxAvg) or sp.gxxAvg != 1 or sp.gradxAvg != 1)
 
+    inner, decorators = _unwrap_flux_model(th.fluxModel)
     model = getattr(th.fluxModel, 'fused_flux_model', None)
     n_points = np.shape(s.x)[-1]
     # the packaged moving average runs inside the fused kernel (grids of up to 4096 points); any other smoother on the host
     fused_smoothing = th.doSmoothing and type(th.fluxSmoother) is _smoother.Smoother and n_points <= 4096 \
         and th.fluxSmoother.windowSize <= n_points
     one = len(s.fields) == 1 and s.fields[0].coupledTo is None and not s.useInnerIteration and th.dxTurbGrid == s.dx
-    if one and model == 'shestakov' and (not th.doSmoothing or fused_smoothing) and not th.isNonCartesian and plain(s.fields[0].lodestroMethod._fluxSplitter) \
-            and getattr(s.fields[0].compute_all_H, 'fused_source', None) is not None and th.fluxModel.dx == s.dx:
-        return _Fused1F(s)
+    builtin = getattr(inner, 'fused_flux_model', None)
+    # the flux models built into the kernel, bare or behind the packaged decorators (taper, device-generated noise), which
+    # then act as the kernel's flux multiplier
+    decorated_ok = not decorators or (n_points <= 4096 and sum(d.flux_decorator == 'noise' for d in decorators) <= 1
+                                      and all(d.flux_decorator == 'taper' or d.device_seed is not None for d in decorators))
+    if one and builtin in ('shestakov', 'power') and decorated_ok and (builtin == 'shestakov' or n_points <= 4096) \
+            and (not th.doSmoothing or fused_smoothing) and not th.isNonCartesian and plain(s.fields[0].lodestroMethod._fluxSplitter) \
+            and getattr(s.fields[0].compute_all_H, 'fused_source', None) is not None and inner.dx == s.dx:
+        return _Fused1F(s, inner, decorators)
     if one and _callback_is_static(s):
         plan = _FusedExternal1F.plan(s)
         if plan is not None:
@@ -428,6 +435,16 @@ def _plan_fused(s):
         from .extras import threefield
         return threefield.plan(s)
     return None
+
+
+def _unwrap_flux_model(model):
+    """(innermost flux model, the packaged decorators around it, outermost first)."""
+    from .extras import bufferzone, noisyflux
+    chain = []
+    while type(model) in (bufferzone.BufferZone, noisyflux.NoisyFlux):
+        chain.append(model)
+        model = model.fluxModel
+    return model, chain
 
 
 def _callback_is_static(s):
@@ -463,12 +480,27 @@ def _callback_is_static(s):
 class _Fused1F(object):
     """Device-resident one-field ensemble stepped by tg_picard_1f_step."""
 
-    def __init__(self, s):
+    def __init__(self, s, model=None, decorators=()):
         f = s.fields[0]
         self.label = f.label
         u0 = np.atleast_2d(np.asarray(s.profiles[f.label], dtype=np.float64))
         self.nb, self.n = u0.shape
         nb = self.nb
+        self.model = model
+        # flux-model decorators: the tapers multiply into one (n,) window, a noise decorator fills an (nb, n) multiplier
+        # on the device before every iteration
+        self.taper = self.mult = self.noise = None
+        tapers = [d for d in decorators if d.flux_decorator == 'taper']
+        if tapers:
+            from .extras.bufferzone import tukey_window
+            w = np.ones(self.n)
+            for d in tapers:
+                w = w * tukey_window(self.n, 2 * d.taperwidth)
+            self.taper = H.DeviceArray.from_host(w)
+        for d in decorators:
+            if d.flux_decorator == 'noise':
+                self.noise = d
+                self.mult = H.DeviceArray((nb, self.n))
         self.u = H.DeviceArray.from_host(u0)
         self.um1 = H.DeviceArray.from_host(np.atleast_2d(np.asarray(f.profile_mminus1, dtype=np.float64)))
         self.uE, self.DE, self.cE = (H.DeviceArray((nb, self.n), zero=True) for _ in range(3))
@@ -506,6 +538,12 @@ class _Fused1F(object):
         if getattr(self, 'work', None) is not None:
             q.work, q.work_bytes = self.work.ptr, self.work.nbytes
         q.flux_model, q.smooth_window, q.fixed_count, q.frozen_turb = H.FLUX_SHESTAKOV, self._smooth_window(s), 0, 0
+        if getattr(getattr(self, 'model', None), 'fused_flux_model', None) == 'power':
+            q.flux_model, q.flux_power = H.FLUX_POWER, float(self.model.p)
+        if getattr(self, 'mult', None) is not None:
+            q.flux_mult, q.flux_mult_stride = self.mult.ptr, self.n
+        elif getattr(self, 'taper', None) is not None:
+            q.flux_mult, q.flux_mult_stride = self.taper.ptr, 0
         # pseudo-timestep control (tango/solver.py:198-216, 311-372) runs inside the kernel
         q.pseudo_time = int(bool(s.useTreadLightly or s.useTreadInitially))
         if s.useTreadLightly:
@@ -545,8 +583,10 @@ class _Fused1F(object):
             q.iterates, q.iterates_rows = snaps.ptr, rows
         stream_hist = hist is not None and snaps is None
         while done < s.maxIterations:
-            k = 1 if stream_hist else min(s.iterationsPerCheck, s.maxIterations - done)
+            k = 1 if (stream_hist or self.noise is not None) else min(s.iterationsPerCheck, s.maxIterations - done)
             q.iters_per_launch = k        # k iterations in one launch, the profiles held in registers in between
+            if self.noise is not None:    # fresh noise for every evaluation of the flux model (tango/extras/noisyflux.py:43-47)
+                self.noise.device_multiplier(self.nb, self.n, out=self.mult, taper=self.taper)
             H.check(H.lib.tg_picard_1f_step(C.byref(self.state), C.byref(q), H.stream()))
             done += k
             if stream_hist:
