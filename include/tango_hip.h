@@ -49,6 +49,9 @@ int tg_device_count(int *count);
 int tg_set_device(int device);
 int tg_malloc(void **ptr, size_t bytes);
 int tg_free(void *ptr);
+/* page-locked host memory: copies between it and the device are asynchronous and run at the full PCIe rate */
+int tg_host_alloc(void **ptr, size_t bytes);
+int tg_host_free(void *ptr);
 int tg_memset(void *ptr, int value, size_t bytes, tg_stream stream);
 int tg_copy_h2d(void *dst, const void *src_host, size_t bytes, tg_stream stream);
 int tg_copy_d2h(void *dst_host, const void *src, size_t bytes, tg_stream stream);
@@ -107,6 +110,12 @@ int tg_residual(const double *A, const double *B, const double *C, const double 
  *      tango/extras/shestakov_nonlinear_diffusion.py:51-61 ------------------------------------- */
 int tg_ewma(const double *y, double *y_ewma_inout, double param, int seeded, int64_t count,
             tg_stream stream);
+/* The EWMA of the profiles of an ensemble as the Picard loop advances it (tango/lodestro_method.py:345, :693-711 with
+ * the loop control of tango/solver.py:150-154): for every profile that still iterates (status has neither
+ * TG_ST_CONVERGED nor TG_ST_INVALID) y_ewma = a y + (1 - a) y_ewma if its memory is seeded (TG_ST_SEEDED), else
+ * a y + (1 - a) y; profiles that have stopped keep their memory.  y, y_ewma: (nb, n); status: (nb,). */
+int tg_ewma_profiles(const double *y, double *y_ewma_inout, double param, const int32_t *status, int64_t nb, int64_t n,
+                     tg_stream stream);
 /* gxx/gradx: optional (n,) shared arrays (NULL = 1).  DHat, cHat, theta: optional outputs. */
 int tg_flux_split(const double *flux, const double *p, double dx, double Dmin, double Dmax,
                   double dpdx_thr, const double *gxx, const double *gradx, double *D, double *c,

@@ -95,6 +95,9 @@ PROTOTYPES = {
     'tg_h_to_matrix': (_int, [_dbl, _p, _dbl, _p, _p, C.POINTER(HCoeffsC), _p, _p, _p, _p, _p, _i64, _i64, _p]),
     'tg_residual': (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     'tg_ewma': (_int, [_p, _p, _dbl, _int, _i64, _p]),
+    'tg_ewma_profiles': (_int, [_p, _p, _dbl, _p, _i64, _i64, _p]),
+    'tg_host_alloc': (_int, [C.POINTER(_p), _sz]),
+    'tg_host_free': (_int, [_p]),
     'tg_flux_split': (_int, [_p, _p, _dbl, _dbl, _dbl, _dbl, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     'tg_ddx': (_int, [_p, _dbl, _int, _p, _i64, _i64, _p]),
     'tg_moving_average': (_int, [_p, _int, _p, _i64, _i64, _p]),
@@ -152,13 +155,21 @@ def synchronize():
 class DeviceArray:
     """A float64 / int32 / int64 array in device memory owned by this object."""
 
-    def __init__(self, shape, dtype=np.float64, zero=False):
+    def __init__(self, shape, dtype=np.float64, zero=False, at=None, owner=None):
+        """at=None: a new allocation owned by this object.  at=<device address>: a window into memory that `owner`
+        keeps alive (a pool): nothing is allocated or freed here."""
         self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         self.dtype = np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
-        ptr = _p()
-        check(lib.tg_malloc(C.byref(ptr), self.nbytes))
-        self.ptr = ptr.value
+        self.owner = owner
+        if at is None:
+            ptr = _p()
+            check(lib.tg_malloc(C.byref(ptr), self.nbytes))
+            self.ptr = ptr.value
+            self._owns = True
+        else:
+            self.ptr = int(at)
+            self._owns = False
         if zero:
             check(lib.tg_memset(self.ptr, 0, self.nbytes, _stream))
 
@@ -213,7 +224,7 @@ class DeviceArray:
 
     def __del__(self):
         p, self.ptr = getattr(self, 'ptr', None), None
-        if p:
+        if p and getattr(self, '_owns', True):
             try:
                 lib.tg_free(p)
             except Exception:
@@ -237,3 +248,36 @@ def ptr_of(a):
 
 def is_device(a):
     return isinstance(a, DeviceArray) or (hasattr(a, 'data_ptr') and getattr(a, 'is_cuda', False))
+
+
+class PinnedArray:
+    """A host array in page-locked memory (copies to and from the device run at full PCIe rate and asynchronously);
+    `.array` is the NumPy view."""
+
+    def __init__(self, shape, dtype=np.float64):
+        self.shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        ptr = _p()
+        check(lib.tg_host_alloc(C.byref(ptr), max(self.nbytes, 8)))
+        self.ptr = ptr.value
+        buf = (C.c_char * max(self.nbytes, 8)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape, dtype=np.int64))).reshape(self.shape)
+
+    def upload(self, dev):
+        """Asynchronous copy into a device array (the caller keeps this buffer unchanged until the stream has passed it)."""
+        check(lib.tg_copy_h2d(ptr_of(dev), self.ptr, self.nbytes, _stream))
+
+    def download(self, dev):
+        check(lib.tg_copy_d2h(self.ptr, ptr_of(dev), self.nbytes, _stream))
+        check(lib.tg_stream_sync(_stream))
+        return self.array
+
+    def __del__(self):
+        p, self.ptr = getattr(self, 'ptr', None), None
+        self.array = None
+        if p:
+            try:
+                lib.tg_host_free(p)
+            except Exception:
+                pass

@@ -264,6 +264,18 @@ __global__ void ewma_kernel(const double *__restrict__ y, double *__restrict__ y
     }
 }
 
+__global__ void ewma_profiles_kernel(const double *__restrict__ y, double *__restrict__ ye, double a, const int32_t *__restrict__ status,
+                                     int64_t nb, int n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = nb * n, stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int st = status[i / n];
+        if (st & (TG_ST_CONVERGED | TG_ST_INVALID)) continue;
+        const double v = y[i];
+        ye[i] = a * v + (1.0 - a) * ((st & TG_ST_SEEDED) ? ye[i] : v);
+    }
+}
+
 __global__ void ddx_kernel(const double *__restrict__ u, double dx, int order, double *__restrict__ out, int64_t nb, int n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = nb * n, stride = (int64_t)gridDim.x * blockDim.x;
@@ -1417,6 +1429,12 @@ int tg_malloc(void **ptr, size_t bytes) {
     return TG_OK;
 }
 int tg_free(void *ptr) { TG_HIP(hipFree(ptr)); return TG_OK; }
+int tg_host_alloc(void **ptr, size_t bytes) {
+    if (!ptr) return fail(TG_ERR_ARG, "ptr is NULL%s");
+    TG_HIP(hipHostMalloc(ptr, bytes ? bytes : 8, hipHostMallocDefault));
+    return TG_OK;
+}
+int tg_host_free(void *ptr) { TG_HIP(hipHostFree(ptr)); return TG_OK; }
 int tg_memset(void *ptr, int value, size_t bytes, tg_stream stream) { TG_HIP(hipMemsetAsync(ptr, value, bytes, S(stream))); return TG_OK; }
 int tg_copy_h2d(void *dst, const void *src, size_t bytes, tg_stream stream) { TG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream))); return TG_OK; }
 int tg_copy_d2h(void *dst, const void *src, size_t bytes, tg_stream stream) { TG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(stream))); return TG_OK; }
@@ -1485,6 +1503,14 @@ int tg_ewma(const double *y, double *y_ewma_inout, double param, int seeded, int
     if (count < 0 || !y || !y_ewma_inout) return fail(TG_ERR_ARG, "bad argument%s");
     if (count == 0) return TG_OK;
     hipLaunchKernelGGL(ewma_kernel, dim3(grid_1d(count, 256)), dim3(256), 0, S(stream), y, y_ewma_inout, param, seeded, count);
+    return launch_check();
+}
+
+int tg_ewma_profiles(const double *y, double *y_ewma_inout, double param, const int32_t *status, int64_t nb, int64_t n, tg_stream stream) {
+    if (int e = check_dims(nb, n, 1)) return e;
+    if (!y || !y_ewma_inout || !status) return fail(TG_ERR_ARG, "NULL array%s");
+    if (nb == 0) return TG_OK;
+    hipLaunchKernelGGL(ewma_profiles_kernel, dim3(grid_1d(nb * n, 256)), dim3(256), 0, S(stream), y, y_ewma_inout, param, status, nb, (int)n);
     return launch_check();
 }
 

@@ -187,6 +187,17 @@ class OneFieldEnsemble:
                                          self.nb, self.n, out_ptr, stream if stream is not None else H.stream()))
 
 
+def device_arrays(shapes_dtypes, zero=False):
+    """One tango_amd.DeviceArray per (shape, dtype), all carved from ONE allocation with skewed offsets (see
+    POOL_SKEW_BYTES): separately allocated power-of-two arrays would all start on the same HBM channel."""
+    pool = Pool(Pool.size_for(shapes_dtypes))
+    out = []
+    for shape, dtype in shapes_dtypes:
+        v = pool.take(shape, dtype)
+        out.append(H.DeviceArray(shape, dtype, zero=zero, at=v.ptr, owner=pool))
+    return out
+
+
 def pooled(shapes_dtypes, alloc=None):
     """One skewed pool holding an array for every (shape, dtype) of the list; returns (pool, views)."""
     pool = Pool(Pool.size_for(shapes_dtypes), alloc)

@@ -101,9 +101,16 @@ def plan(s):
         return None
     if not np.array_equal(np.asarray(fi.compute_all_H.nu0), np.asarray(fe.compute_all_H.nu0)):
         return None
+    th = s.compute_all_H_all_fields.turbhandler
+    if getattr(th.fluxModel, 'dx', None) != s.dx or th.dxTurbGrid != s.dx:
+        return None      # the kernel differentiates on the solver's own grid
     params = [f.lodestroMethod.get_ewma_params() for f in (fn, fi, fe)]
     thetas = [f.lodestroMethod._fluxSplitter.thetaParams for f in (fn, fi, fe)]
     if len(set(params)) != 1 or any(dict(th) != dict(thetas[0]) for th in thetas):
+        return None
+    # EWMA memories handed over by a restart must be there for all three fields or for none
+    preset = [f.lodestroMethod._EWMAProfile._yEWMA_lminus1 is not None for f in (fn, fi, fe)]
+    if any(preset) and not all(preset):
         return None
     return Fused3F(s, (fn, fi, fe))
 
@@ -117,12 +124,21 @@ class Fused3F(object):
         self.nb, self.n = u0[0].shape
         nb, n = self.nb, self.n
         D = H.DeviceArray
-        self.u = [D.from_host(v) for v in u0]
-        self.um1 = [D.from_host(np.atleast_2d(np.asarray(f.profile_mminus1, dtype=np.float64))) for f in fields]
-        self.uE = [D((nb, n), zero=True) for _ in range(3)]
-        self.DE = [D((nb, n), zero=True) for _ in range(3)]
-        self.cE = [D((nb, n), zero=True) for _ in range(3)]
+        from ..ensemble import device_arrays      # the fifteen state arrays: one allocation, skewed offsets
+        arrs = device_arrays([((nb, n), np.float64)] * 15, zero=True)
+        self.u, self.um1, self.uE, self.DE, self.cE = (arrs[3 * k:3 * k + 3] for k in range(5))
+        for k, f in enumerate(fields):
+            self.u[k].set(u0[k])
+            self.um1[k].set(np.atleast_2d(np.asarray(f.profile_mminus1, dtype=np.float64)))
         self.status = D((nb,), np.int32, zero=True)
+        # restart: EWMA memories supplied by the caller (tango/restart.py:90-98) seed the three fields
+        if fields[0].lodestroMethod._EWMAProfile._yEWMA_lminus1 is not None:
+            for k, f in enumerate(fields):
+                m = f.lodestroMethod
+                self.uE[k].set(np.atleast_2d(m._EWMAProfile._yEWMA_lminus1))
+                self.DE[k].set(np.atleast_2d(m._EWMATurbD._yEWMA_lminus1))
+                self.cE[k].set(np.atleast_2d(m._EWMATurbc._yEWMA_lminus1))
+            self.status.set(np.full((nb,), H.ST_SEEDED, np.int32))
         self.iters = D((nb,), np.int32, zero=True)
         self.err = D((nb, s.maxIterations), zero=True)
         self.counts = D((4,), np.int64, zero=True)
@@ -157,7 +173,7 @@ class Fused3F(object):
             H.check(H.lib.tg_memset(self.err.ptr, 0, self.err.nbytes, H.stream()))
         inner = s.innerIterationMaxCount if s.useInnerIteration else 0
         hist = s.profilesAllIterations
-        done = start = s.iterationNumber
+        done = start = self.start = s.iterationNumber
         # The iterate history, when kept, is collected on the device (one copy per field and iteration, no host round
         # trip) and read back once at the end; beyond 256 MiB it is streamed to the host iterate by iterate instead.
         rows = s.maxIterations - done
@@ -198,8 +214,8 @@ class Fused3F(object):
         err = np.zeros(self.err.shape)                 # only the columns that were written cross PCIe
         err[:, :top] = self.err.columns_to_host(top)
         s.iterationsPerProfile = iters.astype(np.int64)
-        s.iterationNumber = int(iters.max())
-        s.countStoredIterations = s.iterationNumber
+        s.countStoredIterations = int(iters.max()) if iters.size else 0
+        s.iterationNumber = getattr(self, 'start', 0) + s.countStoredIterations
         s.converged = bool(np.all(status & H.ST_CONVERGED))
         s.solutionError = bool(np.any(status & H.ST_INVALID))
         s.profileStatus = status

@@ -455,10 +455,12 @@ def _callback_is_static(s):
     f = s.fields[0]
     cb = f.compute_all_H
     flag = getattr(cb, 'static_H', None)
+    s._static_by_trial = False
     if flag is not None:
         return bool(flag)
     if not s.detectStaticH:
         return False
+    s._static_by_trial = True
     try:
         p0 = np.array(s.profiles[f.label], dtype=np.float64)
         p1 = p0 * 1.37 + 0.11 * (1.0 + np.asarray(s.x, dtype=np.float64))
@@ -474,6 +476,9 @@ def _callback_is_static(s):
             return False
         if va is not None and not np.array_equal(np.asarray(va), np.asarray(vb)):
             return False
+    tango_logging.info('compute_all_H of field %r returned the same coefficients for two different profiles and times: its H1 and '
+                       'H7 are evaluated once and the run takes the fused path (checked again at every convergence check; set '
+                       'static_H on the callback, or detectStaticH=False, to decide yourself)' % f.label)
     return True
 
 
@@ -501,9 +506,11 @@ class _Fused1F(object):
             if d.flux_decorator == 'noise':
                 self.noise = d
                 self.mult = H.DeviceArray((nb, self.n))
-        self.u = H.DeviceArray.from_host(u0)
-        self.um1 = H.DeviceArray.from_host(np.atleast_2d(np.asarray(f.profile_mminus1, dtype=np.float64)))
-        self.uE, self.DE, self.cE = (H.DeviceArray((nb, self.n), zero=True) for _ in range(3))
+        # the five state arrays come from one allocation with skewed offsets (ensemble.device_arrays)
+        from .ensemble import device_arrays
+        self.u, self.um1, self.uE, self.DE, self.cE = device_arrays([((nb, self.n), np.float64)] * 5, zero=True)
+        self.u.set(u0)
+        self.um1.set(np.atleast_2d(np.asarray(f.profile_mminus1, dtype=np.float64)))
         self.status = H.DeviceArray((nb,), np.int32, zero=True)
         self.iters = H.DeviceArray((nb,), np.int32, zero=True)
         self.err = H.DeviceArray((nb, s.maxIterations), zero=True)
@@ -665,10 +672,10 @@ class _FusedExternal1F(_Fused1F):
         u0 = np.atleast_2d(np.asarray(s.profiles[f.label], dtype=np.float64))
         self.nb, self.n = nb, n = u0.shape
         D = H.DeviceArray
-        self.u = D.from_host(u0)
-        self.um1 = D.from_host(np.atleast_2d(np.asarray(f.profile_mminus1, dtype=np.float64)))
-        self.uE, self.DE, self.cE = (D((nb, n), zero=True) for _ in range(3))
-        self.flux = D((nb, n), zero=True)
+        from .ensemble import device_arrays
+        self.u, self.um1, self.uE, self.DE, self.cE, self.flux = device_arrays([((nb, n), np.float64)] * 6, zero=True)
+        self.u.set(u0)
+        self.um1.set(np.atleast_2d(np.asarray(f.profile_mminus1, dtype=np.float64)))
         self.status = D((nb,), np.int32, zero=True)
         self.iters = D((nb,), np.int32, zero=True)
         self.err = D((nb, s.maxIterations), zero=True)
@@ -692,6 +699,7 @@ class _FusedExternal1F(_Fused1F):
                 raise ValueError('geometry and H1 coefficients must be one array for the whole ensemble')
             return D.from_host(np.broadcast_to(v, (n,)).copy())
 
+        self._frozen_H = Hs
         self.H1 = grid_array(Hs.H1)
         self.H7, self.h7_stride = None, 0
         if Hs.H7 is not None:
@@ -705,6 +713,23 @@ class _FusedExternal1F(_Fused1F):
             self.Vprime, self.gxx, self.gradx = grid_array(th.VprimeTango), grid_array(th.gxxAvgTango), grid_array(th.gradxAvgTango)
         self.gxx_turb = grid_array(sp.gxxAvg) if (np.ndim(sp.gxxAvg) or sp.gxxAvg != 1) else None
         self.gradx_turb = grid_array(sp.gradxAvg) if (np.ndim(sp.gradxAvg) or sp.gradxAvg != 1) else None
+
+    def _verify_static(self, s):
+        """A callback that was found static by trial calls only (no static_H attribute) is called again at every convergence
+        check with the current time and profiles: if its own coefficients are not the ones frozen at the start, the
+        trial misjudged it (a threshold, a switch in time, internal state) and the run stops rather than go on with
+        coefficients the reference would not use."""
+        if not getattr(s, '_static_by_trial', False):
+            return
+        f = s.fields[0]
+        u = self.u.to_host()
+        now = f.compute_all_H(s.t, s.x, {self.label: u if s.batched else u[0]}, _mf.HCoefficients())
+        for k in ('H1', 'H2', 'H3', 'H4', 'H6', 'H7', 'H8'):
+            a, b = getattr(now, k), getattr(self._frozen_H, k)
+            if (a is None) != (b is None) or (a is not None and not np.array_equal(np.asarray(a), np.asarray(b))):
+                raise RuntimeError('compute_all_H of field %r looked independent of the profile and of time in two trial calls, but '
+                                   'its %s has changed at t = %g: construct the Solver with detectStaticH=False (or give the '
+                                   'callback an attribute static_H = False)' % (self.label, k, s.t))
 
     def params(self, s):
         q = _Fused1F.params(self, s)
@@ -735,29 +760,33 @@ class _FusedExternal1F(_Fused1F):
         if getattr(th.fluxModel, 'device_flux', False) and not host_smoothing:
             return self._run_timestep_device_flux(s, q, th, a_prof)
         pick = (lambda a: a) if s.batched else (lambda a: a[0])
-        u = self.u.to_host()
+        # Host side of the protocol, per iteration: the profile EWMA of the members that still iterate is advanced on the
+        # device (tg_ewma_profiles), comes to the host through a page-locked buffer, the flux model (and a smoother the
+        # kernel does not implement) runs on it, the flux goes back through another page-locked buffer.  Whether anything
+        # still iterates is looked up every iterationsPerCheck iterations only.
+        if getattr(self, '_pinned', None) is None:
+            self._pinned = (H.PinnedArray((self.nb, self.n)), H.PinnedArray((self.nb, self.n)))
+        uE_pin, flux_pin = self._pinned
         while done < s.maxIterations:
-            status = self.status.to_host()
-            active = (status & (H.ST_CONVERGED | H.ST_INVALID)) == 0
-            if not active.any():
-                break
-            # host side of the protocol: EWMA of the profiles that still iterate, flux model, smoothing
-            if self.uE_host is None:        # first iterate, or memory left on the device by a device flux model
-                self.uE_host = self.uE.to_host() if getattr(self, '_uE_on_device', False) else u.copy()
-            new = a_prof * u + (1 - a_prof) * self.uE_host
-            self.uE_host[active] = new[active]
-            flux = np.asarray(th.fluxModel.get_flux({self.label: pick(self.uE_host)})[self.label], dtype=np.float64)
+            if (done - self.start) % s.iterationsPerCheck == 0:
+                H.check(H.lib.tg_status_reduce(self.status.ptr, self.nb, self.counts.ptr, H.stream()))
+                if int(self.counts.to_host()[0]) == 0:
+                    break
+                self._verify_static(s)
+            H.check(H.lib.tg_ewma_profiles(self.u.ptr, self.uE.ptr, float(a_prof), self.status.ptr, self.nb, self.n, H.stream()))
+            uE_host = uE_pin.download(self.uE)
+            flux = np.asarray(th.fluxModel.get_flux({self.label: pick(uE_host)})[self.label], dtype=np.float64)
             if host_smoothing:
                 flux = np.asarray(th.fluxSmoother.smooth(flux), dtype=np.float64)
-            self.uE.set(self.uE_host)
-            self.flux.set(np.atleast_2d(flux))
+            flux_pin.array[...] = np.atleast_2d(flux)
+            flux_pin.upload(self.flux)
             H.check(H.lib.tg_picard_1f_step(C.byref(self.state), C.byref(q), H.stream()))
             done += 1
-            u = self.u.to_host()          # the new iterate: history row and input of the next profile EWMA
             if hist is not None:
-                hist[self.label][done - 1 - self.start] = pick(u)
+                hist[self.label][done - 1 - self.start] = pick(self.u.to_host())
                 if s.fluxesAllIterations is not None:
                     s.fluxesAllIterations[self.label][done - 1 - self.start] = flux
+        self._uE_on_device = True
         self.finish(s)
 
     def _run_timestep_device_flux(self, s, q, th, a_prof):
@@ -779,18 +808,17 @@ class _FusedExternal1F(_Fused1F):
         previous = H.stream()
         H.set_stream(torch.cuda.current_stream().cuda_stream)
         try:
-            seeded = self.uE_host is not None or getattr(self, '_uE_on_device', False)
             done = self.start
             while done < s.maxIterations:
-                active = (st_t & (H.ST_CONVERGED | H.ST_INVALID)) == 0
-                if (done - self.start) % s.iterationsPerCheck == 0 and not bool(active.any()):
-                    break
-                # EWMA of the profiles that still iterate (tango/lodestro_method.py:345), the first one seeding the memory
-                if not seeded:
-                    uE_t.copy_(u_t)
-                    seeded = self._uE_on_device = True
-                new = a_prof * u_t + (1 - a_prof) * uE_t
-                uE_t.copy_(torch.where(active[:, None], new, uE_t))
+                if (done - self.start) % s.iterationsPerCheck == 0:
+                    H.check(H.lib.tg_status_reduce(self.status.ptr, self.nb, self.counts.ptr, H.stream()))
+                    if int(self.counts.to_host()[0]) == 0:
+                        break
+                    self._verify_static(s)
+                # EWMA of the profiles that still iterate (tango/lodestro_method.py:345), the first one seeding the memory:
+                # one kernel on the same stream, predicated on the status word
+                H.check(H.lib.tg_ewma_profiles(self.u.ptr, self.uE.ptr, float(a_prof), self.status.ptr, self.nb, self.n, H.stream()))
+                self._uE_on_device = True
                 flux = th.fluxModel.get_flux({self.label: uE_t if s.batched else uE_t[0]})[self.label]
                 fl_t.copy_(torch.as_tensor(flux, device=dev).reshape(self.nb, self.n))
                 H.check(H.lib.tg_picard_1f_step(C.byref(self.state), C.byref(q), H.stream()))

@@ -88,7 +88,7 @@ def test_block3_solve(tango, n):
     assert relerr(x1[:, 0], u0) < 1e-12 and relerr(x1[:, 1], u1) < 1e-12 and relerr(x1[:, 2], u2) < 1e-12
 
 
-def make_3f_solver(tango, N, nu0, BCs, tol=1e-9, maxit=1000, inner=0, fused=True, ic=None, ewma=(0.3, 0.3), dt=1e6, **kw):
+def make_3f_solver(tango, N, nu0, BCs, tol=1e-9, maxit=1000, inner=0, fused=True, ic=None, ewma=(0.3, 0.3), dt=1e6, ewma_iterates=None, **kw):
     T = tango.extras.threefield
     dx = 1 / (N - 1); x = np.arange(N) * dx
     th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
@@ -97,6 +97,9 @@ def make_3f_solver(tango, N, nu0, BCs, tol=1e-9, maxit=1000, inner=0, fused=True
     if not fused:     # plain callables -> generic path
         cbs = [(lambda cb: (lambda t, xx, p, HT: cb(t, xx, p, HT)))(cb) for cb in cbs]
     lms = [tango.lodestro_method.lm(ewma[0], ewma[1], th) for _ in range(3)]
+    if ewma_iterates is not None:      # continuing an interrupted run: (profile, D, c) memories of the three fields
+        for m_, its_ in zip(lms, ewma_iterates):
+            m_.set_ewma_iterates(*its_)
     F = tango.multifield.Field
     fields = [F(label='n', rightBC=BCs[0], profile_mminus1=1.0 * ic, compute_all_H=cbs[0], lodestroMethod=lms[0]),
               F(label='pi', rightBC=BCs[1], profile_mminus1=1.0 * ic, compute_all_H=cbs[1], lodestroMethod=lms[1], coupledTo='pe'),
@@ -137,6 +140,33 @@ def test_threefield_inner_iteration(tango, golden):
     for lab in ('n', 'pi', 'pe'):
         assert relerr(s.profiles[lab], g[f'inner_{lab}']) < TOL
         assert relerr(s.profilesAllIterations[lab][0], g[f'inner_it0_{lab}']) < TOL
+
+
+@pytest.mark.parametrize('nb', [1, 3])
+def test_threefield_interrupt_and_continue(tango, nb):
+    """A three-field run stopped after 9 iterations and continued in a new Solver from the profiles and the EWMA memories
+    (tango/restart.py:90-98, tango/solver.py:109) follows the uninterrupted run; the iteration number carries on."""
+    N = 256
+    if nb == 1:
+        nu0, BCs, ic = 2.2, (2, 0.1, 0.3), None
+    else:
+        ens = orc.threefield_ensemble(nb, N)
+        nu0, BCs, ic = ens['nu0'], tuple(ens['bc'][:, k].copy() for k in range(3)), ens['u0']
+    whole, _ = make_3f_solver(tango, N, nu0, BCs, tol=1e-30, maxit=20, ic=ic)
+    whole.take_timestep()
+    part, lms = make_3f_solver(tango, N, nu0, BCs, tol=1e-30, maxit=9, ic=ic)
+    part.take_timestep()
+    assert part.countLastTimestep == 9
+    memories = [tuple(np.array(v) for v in (m._EWMAProfile._yEWMA_lminus1, m._EWMATurbD._yEWMA_lminus1, m._EWMATurbc._yEWMA_lminus1))
+                for m in lms]
+    cont, _ = make_3f_solver(tango, N, nu0, BCs, tol=1e-30, maxit=20, ic=ic, ewma_iterates=memories,
+                             profiles={k: np.array(v) for k, v in part.profiles.items()}, startIterationNumber=9)
+    assert cont._fused is not None
+    cont.take_timestep()
+    assert cont.countLastTimestep == 20 and np.shape(cont.errHistoryFinal)[-1] == 11
+    for lab in ('n', 'pi', 'pe'):
+        assert relerr(cont.profiles[lab], whole.profiles[lab]) < 1e-12
+    assert np.allclose(cont.errHistoryFinal, whole.errHistoryFinal[..., 9:20], rtol=1e-9, atol=1e-15)
 
 
 def test_threefield_generic_path(tango, golden):

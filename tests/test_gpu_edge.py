@@ -136,3 +136,32 @@ def test_restart_file_round_trip(tango, tmp_path, monkeypatch):
     fn2 = tango.restart.write_state(cont, basename='run', setNumber=setNumber)
     assert tango.restart.find_latest_savefile('run') == fn2 == 'run_s1.npz'
     assert tango.restart.read_metadata_from_previousfile(fn2)[1] == 30
+
+
+def test_static_callback_found_by_trial_is_checked_again(tango):
+    """A callback that looks independent of profiles and time in the two trial calls but is not (here: it counts its
+    calls) is caught at a convergence check instead of silently running with frozen coefficients."""
+    N = 128
+    x = np.arange(N) * (1 / (N - 1))
+    sh = tango.extras.shestakov_nonlinear_diffusion
+    calls = [0]
+
+    class PowerFlux(object):
+        def __init__(self, dx):
+            self.dx = dx
+
+        def get_flux(self, profiles):
+            return {'n': np.asarray(sh.get_flux(profiles['n'], self.dx))}
+
+    def cb(t, xx, profiles, HT):
+        calls[0] += 1
+        amp = 1.0 if calls[0] <= 4 else 2.0           # the source doubles after the fourth call
+        return tango.multifield.HCoefficients(H1=np.ones_like(xx), H7=amp * sh.GetSource(xx)) + HT
+    lm = tango.lodestro_method.lm(0.3, 1.0, {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10})
+    f = tango.multifield.Field(label='n', rightBC=1e-2, profile_mminus1=1 - 0.5 * x, compute_all_H=cb, lodestroMethod=lm)
+    tango.multifield.check_fields_initialize([f])
+    call = tango.multifield.ComputeAllHAllFields([f], tango.lodestro_method.TurbulenceHandler(x[1] - x[0], x, PowerFlux(x[1] - x[0])))
+    s = tango.solver.Solver(1, x, np.array([0, 1e4]), 50, 1e-30, call, [f], iterationsPerCheck=5)
+    assert type(s._fused).__name__ == '_FusedExternal1F' and s._static_by_trial
+    with pytest.raises(RuntimeError, match='detectStaticH'):
+        s.take_timestep()
