@@ -1,6 +1,9 @@
 """Build libtango_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python tango_amd/build.py [--report] [--asan-host]   (run as a script: importing the package needs the built library)
+    python tango_amd/build.py [--report] [--asan-host] [--host-check]   (run as a script: importing the package needs the built library)
+
+--asan-host builds lib/libtango_hip_asan.so with AddressSanitizer on the host code (the device code is left alone);
+--host-check builds that and runs csrc/host_check.cpp against it (every entry point's argument checks, no GPU needed).
 
 The library is written in-tree to tango_amd/lib/ so that it travels with the source tree.  The translation units
 are compiled side by side and linked afterwards.
@@ -92,7 +95,24 @@ def build(report=False, force=False, asan_host=False, extra_flags=(), out=None):
     return out
 
 
+def host_check(lib):
+    """Build and run csrc/host_check.cpp against a (sanitizer) build of the library: every entry point's argument
+    validation, no GPU needed.  Returns the program's output; raises if it fails."""
+    exe = os.path.join(os.path.dirname(lib), 'host_check')
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    _run([hipcc, '-x', 'c++', '-std=c++17', '-O1', '-g', '-fsanitize=address', '-fno-omit-frame-pointer',
+          os.path.join(HERE, 'csrc', 'host_check.cpp'), '-x', 'none', lib, '-Wl,-rpath,' + os.path.dirname(lib), '-o', exe])
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=0:protect_shadow_gap=0:verify_asan_link_order=0')
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+    if r.returncode != 0:
+        raise RuntimeError('host_check failed:\n' + r.stdout)
+    return r.stdout
+
+
 if __name__ == '__main__':
+    if '--host-check' in sys.argv:
+        print(host_check(build(asan_host=True)))
+        sys.exit(0)
     print(build(report='--report' in sys.argv, force=True, asan_host='--asan-host' in sys.argv,
                 extra_flags=['-ffp-contract=off'] if '--contract-off' in sys.argv else (),
                 out=OUT.replace('.so', '_nocontract.so') if '--contract-off' in sys.argv else None))

@@ -50,6 +50,31 @@ __device__ __forceinline__ double quot(double n, double d) {
     }
 }
 
+// Neighbour exchange over the whole wavefront by data-parallel-primitive moves (no trip through the LDS crossbar):
+// lane t receives the value of lane t-1 (wave_shr:1) or t+1 (wave_shl:1); the lane at the end keeps its own value.
+__device__ __forceinline__ double dpp_from_lane_below(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_lane_above(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Exchange between the two halves of a wavefront: lane t receives the value of lane t ^ 32 (one v_permlane32_swap per
+// dword and a select, no trip through the LDS crossbar).
+__device__ __forceinline__ double swap_halves(double v, bool upper) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    // element 0: lanes 32-63 hold the lower half's values; element 1: lanes 0-31 hold the upper half's values
+    return __hiloint2double((int)(upper ? b[0] : b[1]), (int)(upper ? a[0] : a[1]));
+}
+
 template <int LPP>
 struct WaveGroup {
     static constexpr int T = LPP;
@@ -63,11 +88,15 @@ struct WaveGroup {
 
     // value held by lane t-h (fill when there is none)
     __device__ double from_left(double v, int h, double fill) const {
-        double r = __shfl_up(v, (unsigned)h, LPP);
+        double r;
+        if (LPP == 64 && __builtin_constant_p(h) && h == 1) r = dpp_from_lane_below(v);
+        else r = __shfl_up(v, (unsigned)h, LPP);
         return (t_ >= h) ? r : fill;
     }
     __device__ double from_right(double v, int h, double fill) const {
-        double r = __shfl_down(v, (unsigned)h, LPP);
+        double r;
+        if (LPP == 64 && __builtin_constant_p(h) && h == 1) r = dpp_from_lane_above(v);
+        else r = __shfl_down(v, (unsigned)h, LPP);
         return (t_ + h < LPP) ? r : fill;
     }
     // CNT values from the lanes t-h (l) and t+h (r), zeros where there is no such lane
@@ -128,10 +157,14 @@ struct WaveGroup {
         p = (t_ == LPP - 1) ? 0.0 : p;
 #pragma unroll
         for (int h = 1; h < LPP; h <<= 1) {
-            const double sm = __shfl_up(s, (unsigned)h, LPP), rm = __shfl_up(r, (unsigned)h, LPP);
-            const double dm = __shfl_up(dl, (unsigned)h, LPP);
-            const double pp = __shfl_down(p, (unsigned)h, LPP), rp = __shfl_down(r, (unsigned)h, LPP);
-            const double dp = __shfl_down(dl, (unsigned)h, LPP);
+            double sm, rm, dm, pp, rp, dp;
+            if (LPP == 64 && h == 1) {      // nearest neighbours over a whole wavefront: DPP moves
+                sm = dpp_from_lane_below(s), rm = dpp_from_lane_below(r), dm = dpp_from_lane_below(dl);
+                pp = dpp_from_lane_above(p), rp = dpp_from_lane_above(r), dp = dpp_from_lane_above(dl);
+            } else {
+                sm = __shfl_up(s, (unsigned)h, LPP), rm = __shfl_up(r, (unsigned)h, LPP), dm = __shfl_up(dl, (unsigned)h, LPP);
+                pp = __shfl_down(p, (unsigned)h, LPP), rp = __shfl_down(r, (unsigned)h, LPP), dp = __shfl_down(dl, (unsigned)h, LPP);
+            }
             const double d2 = dl - s * dm - p * dp;
             const double s2 = -(sm * s);
             const double p2 = -(pp * p);
@@ -142,6 +175,19 @@ struct WaveGroup {
             s = s2 * inv;
             p = p2 * inv;
             dl = d2 * inv;
+            if (LPP == 64 && h == 16) break;      // the last level of a whole wavefront is done below
+        }
+        if constexpr (LPP == 64) {
+            // Distance 32: a lane of the lower half has no left neighbour (s = 0 exactly, see above) and a lane of the upper
+            // half no right one (p = 0), so the value of lane t ^ 32 serves as both neighbours (the absent one is
+            // multiplied by zero), and the new couplings s2 = -(sm s), p2 = -(pp p) are zero: sm and pp come from lanes
+            // whose own s and p are zero.  The results are those of the general level, bit for bit.
+            const bool upper = t_ >= 32;
+            const double rx = swap_halves(r, upper), dx = swap_halves(dl, upper);
+            const double d2 = dl - s * dx - p * dx;
+            singular |= (d2 == 0.0);
+            const double inv = recip<FAST>(d2);
+            r = (r - rx * s - rx * p) * inv;
         }
         return r;
     }
