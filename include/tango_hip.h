@@ -311,6 +311,14 @@ typedef struct {
     int32_t outer_count; /* frozen passes only: process the profiles whose iteration count equals this value (those
                             that took part in the outer iteration just made, converged by it or not) */
     int32_t reserved_;
+    /* Pseudo-timestep control, as in tg_params_1f (tango/solver.py:198-216, :233-235, :311-372); a step is redone with a
+     * halved pseudo-timestep when ANY of the three profiles changed too much.  Not together with frozen_turb. */
+    int32_t pseudo_time;
+    int32_t tread_lightly;
+    int32_t tread_inner_count;
+    int32_t tread_initial_steps;
+    double tread_max_change;
+    double tread_initial_dtau;
 } tg_params_3f;
 
 int tg_picard_3f_step(const tg_state_3f *state, const tg_params_3f *params, tg_stream stream);

@@ -720,6 +720,52 @@ def picard_step_3f(st, dt, dx, BCs, nu0, x, a_turb, a_prof, theta=THETA_DEFAULT,
     return rms, profiles_invalid([fn.u, fi.u, fe.u]), frozen
 
 
+def picard_step_3f_tread(st, it, dt, dx, BCs, nu0, x, a_turb, a_prof, theta=THETA_DEFAULT, tread_lightly=None,
+                         tread_initially=None, tri=tridiag_solve, pair=pair_solve):
+    """One iteration of the three-field problem with the pseudo-timestep controls of tango/solver.py:198-235,
+    :311-372: the previous iterates take the u_{m-1} slots; a step that moves ANY of the three profiles too far
+    (:374-402) is redone from the previous iterates with the same turbulent coefficients, the collision frequency of
+    the previous iterates (the callbacks are re-evaluated on them) and dtau = dt/2, dt/4, ...
+    Returns (rms residual, invalid flag, number of halvings)."""
+    for s in st.f:
+        s.um1 = s.u
+    dtau = dt
+    if tread_initially is not None and it < tread_initially['numInitialSteps']:
+        dtau = tread_initially['dtau']
+    old = [s.u for s in st.f]
+    rms, bad, frozen = picard_step_3f(st, dtau, dx, BCs, nu0, x, a_turb, a_prof, theta, tri, pair)
+    halvings = 0
+    if tread_lightly is not None:
+        kw = dict(max_fractional_change=tread_lightly.get('maxFractionalChange', 0.2),
+                  inner_fraction=tread_lightly.get('innerFraction', 0.5))
+        far = lambda: any(is_unacceptable(o, s.u, **kw) for o, s in zip(old, st.f))
+        dtau = dt
+        while far():
+            dtau /= 2
+            halvings += 1
+            for s, o in zip(st.f, old):
+                s.u = o
+            _, bad, _ = picard_step_3f(st, dtau, dx, BCs, nu0, x, a_turb, a_prof, theta, tri, pair, turbulence=False, frozen=frozen)
+    return rms, bad, halvings
+
+
+def run_3f_tread(n0, pi0, pe0, dt, dx, BCs, nu0, x, a_turb, a_prof, tol, max_iter, tread_lightly=None, tread_initially=None,
+                 theta=THETA_DEFAULT):
+    """One timestep of one three-field profile with pseudo-timestep control; returns ((n, pi, pe), iterations, errHistory,
+    all iterates (iterations, 3, N), halvings per iteration)."""
+    st = State3F(n0, pi0, pe0)
+    err, hist, halv = [], [], []
+    it = 0
+    done = bad = False
+    while it < max_iter and not done and not bad:
+        rms, bad, h = picard_step_3f_tread(st, it, dt, dx, BCs, nu0, x, a_turb, a_prof, theta, tread_lightly, tread_initially)
+        err.append(rms); hist.append(np.stack([s.u for s in st.f])); halv.append(h)
+        done = bool(rms < tol)
+        bad = bool(bad)
+        it += 1
+    return tuple(s.u for s in st.f), it, np.array(err), np.array(hist), np.array(halv)
+
+
 def run_3f(n0, pi0, pe0, dt, dx, BCs, nu0, x, a_turb, a_prof, tol, max_iter,
            theta=THETA_DEFAULT, inner=0, tri=tridiag_solve, pair=pair_solve,
            fixed_count=False):

@@ -67,7 +67,9 @@ class State3F(C.Structure):
 class Params3F(C.Structure):
     _fields_ = [('dt', _dbl), ('dx', _dbl), ('a_turb', _dbl), ('a_prof', _dbl), ('Dmin', _dbl), ('Dmax', _dbl),
                 ('dpdx_thr', _dbl), ('tol', _dbl), ('UL', _p * 3), ('H7', _p * 3), ('nu0', _p), ('fixed_count', C.c_int32),
-                ('frozen_turb', C.c_int32), ('outer_count', C.c_int32), ('reserved_', C.c_int32)]
+                ('frozen_turb', C.c_int32), ('outer_count', C.c_int32), ('reserved_', C.c_int32), ('pseudo_time', C.c_int32),
+                ('tread_lightly', C.c_int32), ('tread_inner_count', C.c_int32), ('tread_initial_steps', C.c_int32),
+                ('tread_max_change', _dbl), ('tread_initial_dtau', _dbl)]
 
 
 # every exported symbol of include/tango_hip.h with its prototype

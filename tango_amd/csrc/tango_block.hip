@@ -138,7 +138,11 @@ block3_solve_kernel(const double *__restrict__ Cb, const double *__restrict__ Bb
 constexpr int kTiles3f = 4;
 constexpr int kExch3f = 18;     // doubles per thread of the workgroup exchange area
 
-template <int P, class G, bool FULL>
+// TREAD: pseudo-timestep control (tango/solver.py:198-216, :311-372 for three fields): the previous iterates take the
+// u_{m-1} slots, the first iterations of a profile may use a short pseudo-timestep, and a step that moves any of the
+// three profiles too far is redone from the previous iterates with dtau = dt/2, dt/4, ... (same turbulent coefficients,
+// same collision frequency) until acceptable.
+template <int P, class G, bool FULL, bool TREAD>
 __global__ void __launch_bounds__(G::kBlock ? G::T : 256)
 picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     extern __shared__ double lds[];
@@ -157,7 +161,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     const int t = g.t();
     const int j0 = t * P;
     const int64_t off = b * S_.n;
-    const Recip rc(Q.dx, Q.dt);
+    // treadInitially's short pseudo-timestep for a profile's first iterations (tango/solver.py:210-215)
+    Recip rc(Q.dx, (TREAD && it < Q.tread_initial_steps) ? Q.tread_initial_dtau : Q.dt);
     const bool lane_first = (t == 0);
     const Theta th(Q.Dmin, Q.Dmax, Q.dpdx_thr);
     const double omp = 1.0 - Q.a_prof, omt = 1.0 - Q.a_turb;
@@ -186,8 +191,10 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
 #pragma unroll
             for (int s = 0; s < 3; ++s) wt.fetch(S_.uE[s] + woff, rE[s]);
         }
+        if constexpr (!TREAD) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) wt.fetch(S_.um1[s] + woff, rm[s]);
+            for (int s = 0; s < 3; ++s) wt.fetch(S_.um1[s] + woff, rm[s]);
+        }
         wt.stage(0, ru[0]); wt.stage(1, ru[1]); wt.stage(2, ru[2]); wt.stage(3, rD[0]);
         Tile::sync();
         wt.take(0, u[0] + 1); wt.take(1, u[1] + 1); wt.take(2, u[2] + 1); wt.take(3, DE[0]);
@@ -334,8 +341,10 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         for (int s = 0; s < 3; ++s) u[s][0] = 0.0;
     }
 
-    double um1[3][P];
-    if constexpr (COOP) {
+    double um1[3][TREAD ? 1 : P];
+    if constexpr (TREAD) {
+        // the previous iterate takes the u_{m-1} slot (tango/solver.py:198-201): read from u below
+    } else if constexpr (COOP) {
         wt.stage(0, rm[0]); wt.stage(1, rm[1]); wt.stage(2, rm[2]);
         Tile::sync();
         wt.take(0, um1[0]); wt.take(1, um1[1]); wt.take(2, um1[2]);
@@ -349,6 +358,14 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) UL[s] = Q.UL[s][b];
 
+    double xn[P];
+    Vec<2> xp[P];
+    double rms = 0.0;
+    int singular = 0;
+    bool settled = false, tread_limit = false;
+    double dtau = Q.dt;
+#pragma unroll 1
+    for (int attempt = 0;; ++attempt) {
     ChunkElim<P, DIV> eln;
     BlockElim<2, P, DIV> elp;
     double hm2[3], hm3[3], bm[3], h2c[3], h3c[3];
@@ -379,7 +396,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             const double hp3 = (h3c[s] + h3n) / 2.0;
             const double bp = fbeta_point<DIV>(hp2, hp3, rc.dx);
             const double h6 = (s == 0) ? 0.0 : -nu;       // H6 = -nu for pi and pe (example :125, :144)
-            fd_row<EXACT>(last, 1.0, um1[s][i], rc, UL[s], hm2[s], hm3[s], bm[s], hp2, hp3, bp, 0.0, h6, Q.H7[s][jc], A[s], B[s],
+            fd_row<EXACT>(last, 1.0, TREAD ? u[s][i + 1] : um1[s][TREAD ? 0 : i], rc, UL[s], hm2[s], hm3[s], bm[s], hp2, hp3, bp, 0.0, h6, Q.H7[s][jc], A[s], B[s],
                          C[s], f[s]);
             if (!valid) {
                 A[s] = 0.0; B[s] = 1.0; C[s] = 0.0; f[s] = 0.0;
@@ -417,16 +434,52 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         d.v[1] = f[2];
         elp.push(i, Cm, Bm, Am, d);
     }
-    double tot = 0.0;
-    g.template max_and_sum<3>(mx, ss);
+    // rms of the three normalised residuals (tango/solver.py:464-470): the first solve's matrix decides
+    if (attempt == 0) {
+        double tot = 0.0;
+        g.template max_and_sum<3>(mx, ss);
 #pragma unroll
-    for (int s = 0; s < 3; ++s) tot += ss[s] / (mx[s] * mx[s]);
-    const double rms = sqrt(1.0 / (3.0 * (double)n) * tot);
-
-    double xn[P];
-    Vec<2> xp[P];
-    eln.finish(g, xn);
-    elp.finish(g, xp);
+        for (int s = 0; s < 3; ++s) tot += ss[s] / (mx[s] * mx[s]);
+        rms = sqrt(1.0 / (3.0 * (double)n) * tot);
+    }
+    double tn[P];
+    Vec<2> tp[P];
+    eln.finish(g, tn);
+    elp.finish(g, tp);
+    if constexpr (!TREAD) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            xn[i] = tn[i];
+            xp[i] = tp[i];
+        }
+        singular = eln.singular | elp.singular;
+        break;
+    } else {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            xn[i] = settled ? xn[i] : tn[i];
+            xp[i].v[0] = settled ? xp[i].v[0] : tp[i].v[0];
+            xp[i].v[1] = settled ? xp[i].v[1] : tp[i].v[1];
+        }
+        singular |= settled ? 0 : (eln.singular | elp.singular);
+        if (!Q.tread_lightly) break;
+        // tango/solver.py:374-402, :564-595: a change of maxFractionalChange or more anywhere in the inner part of ANY profile
+        int far = 0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const bool in = j0 + i < Q.tread_inner_count;
+            far |= in && (fabs((tn[i] - u[0][i + 1]) / u[0][i + 1]) >= Q.tread_max_change);
+            far |= in && (fabs((tp[i].v[0] - u[1][i + 1]) / u[1][i + 1]) >= Q.tread_max_change);
+            far |= in && (fabs((tp[i].v[1] - u[2][i + 1]) / u[2][i + 1]) >= Q.tread_max_change);
+        }
+        far = g.any(far);
+        if (!settled && far && attempt >= TG_TREAD_MAX_HALVINGS) tread_limit = true;
+        settled = settled || !far || attempt >= TG_TREAD_MAX_HALVINGS;
+        if (G::kBlock ? settled : !__any(!settled)) break;
+        dtau = settled ? dtau : dtau / 2.0;
+        rc = Recip(Q.dx, dtau);
+    }
+    }   // attempts
     double xi[P], xe[P];
     int bad = 0;
 #pragma unroll
@@ -444,7 +497,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         store_chunk<P, false>(S_.u[1] + off, n, j0, xi);
         store_chunk<P, false>(S_.u[2] + off, n, j0, xe);
     }
-    bad = g.any(bad | ((eln.singular | elp.singular) << 1));
+    bad = g.any(bad | (singular << 1));
     if (t == 0) {
         int ns = st;
         if (!Q.frozen_turb) {
@@ -455,6 +508,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         }
         if (bad & 1) ns |= TG_ST_INVALID;
         if (bad & 2) ns |= TG_ST_SINGULAR;
+        if (tread_limit) ns |= TG_ST_TREAD_LIMIT;
         S_.status[b] = ns;
     }
 }
@@ -513,11 +567,13 @@ struct Picard3fLauncher {
         const size_t cap = max_lds_bytes();
         if (lds > cap) return fail(TG_ERR_UNSUPPORTED, "grid too large for the LDS of this device%s");
         const bool full = (n == P * G::T) && (al & 15) == 0 && (P == 4 || P == 8) && (G::kBlock || G::T == 64) && lds + tiles <= cap;
-        if (full) {
-            lds += tiles;
-            hipLaunchKernelGGL((picard_3f_kernel<P, G, true>), dim3(grid), dim3(block), lds, s, *st, *q);
+        if (full) lds += tiles;
+        if (q->pseudo_time) {
+            if (full) hipLaunchKernelGGL((picard_3f_kernel<P, G, true, true>), dim3(grid), dim3(block), lds, s, *st, *q);
+            else hipLaunchKernelGGL((picard_3f_kernel<P, G, false, true>), dim3(grid), dim3(block), lds, s, *st, *q);
         } else {
-            hipLaunchKernelGGL((picard_3f_kernel<P, G, false>), dim3(grid), dim3(block), lds, s, *st, *q);
+            if (full) hipLaunchKernelGGL((picard_3f_kernel<P, G, true, false>), dim3(grid), dim3(block), lds, s, *st, *q);
+            else hipLaunchKernelGGL((picard_3f_kernel<P, G, false, false>), dim3(grid), dim3(block), lds, s, *st, *q);
         }
         return launch_check();
     }
@@ -554,6 +610,13 @@ int tg_picard_3f_step(const tg_state_3f *st, const tg_params_3f *q, tg_stream st
     }
     if (!st->status || !st->iters || !q->nu0) return fail(TG_ERR_ARG, "NULL status, iters or nu0%s");
     if (st->err && st->err_stride <= 0) return fail(TG_ERR_ARG, "err_stride must be positive%s");
+    if ((q->tread_lightly || q->tread_initial_steps > 0) && !q->pseudo_time)
+        return fail(TG_ERR_ARG, "tread_lightly and tread_initial_steps need pseudo_time (the previous iterates in the u_{m-1} slots)%s");
+    if (q->pseudo_time && q->frozen_turb) return fail(TG_ERR_UNSUPPORTED, "pseudo-timestep control and inner iterations do not combine%s");
+    if (q->tread_lightly && (q->tread_inner_count < 0 || q->tread_inner_count > st->n || !(q->tread_max_change > 0.0)))
+        return fail(TG_ERR_ARG, "tread_lightly needs 0 <= tread_inner_count <= n and tread_max_change > 0%s");
+    if (q->tread_initial_steps < 0 || (q->tread_initial_steps > 0 && !(q->tread_initial_dtau > 0.0)))
+        return fail(TG_ERR_ARG, "tread_initial_steps needs tread_initial_dtau > 0%s");
     if (st->nb == 0) return TG_OK;
     return dispatch_block<Picard3fLauncher>(st->nb, (int)st->n, 1024, S(stream), st, q);
 }

@@ -161,6 +161,15 @@ class Fused3F(object):
         q.Dmin, q.Dmax, q.dpdx_thr, q.tol = float(tp['Dmin']), float(tp['Dmax']), float(tp['dpdxThreshold']), float(s.tol)
         q.UL, q.H7, q.nu0 = self._ptrs(self.UL), self._ptrs(self.H7), self.nu0.ptr
         q.fixed_count, q.frozen_turb, q.outer_count = 0, 0, 0
+        # pseudo-timestep control (tango/solver.py:198-216, 311-372) runs inside the kernel
+        q.pseudo_time = int(bool(s.useTreadLightly or s.useTreadInitially))
+        if s.useTreadLightly:
+            q.tread_lightly = 1
+            q.tread_max_change = float(s.treadLightlyParams.get('maxFractionalChange', 0.2))
+            q.tread_inner_count = int(s.treadLightlyParams.get('innerFraction', 0.5) * self.n)
+        if s.useTreadInitially:
+            q.tread_initial_steps = int(s.treadInitiallyParams['numInitialSteps'])
+            q.tread_initial_dtau = float(s.treadInitiallyParams['dtau'])
         return q
 
     def run_timestep(self, s):

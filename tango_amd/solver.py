@@ -429,8 +429,8 @@ def _plan_fused(s):
             return plan
     if th.doSmoothing or th.isNonCartesian or not all(plain(f.lodestroMethod._fluxSplitter) for f in s.fields):
         return None
-    if s.useTreadLightly or s.useTreadInitially:
-        return None      # pseudo-timestep control is built into the one-field kernel only
+    if (s.useTreadLightly or s.useTreadInitially) and s.useInnerIteration:
+        return None      # the kernels do not combine pseudo-timestep control with inner iterations
     if model == 'threefield_nonlinear_nu' and len(s.fields) == 3:
         from .extras import threefield
         return threefield.plan(s)

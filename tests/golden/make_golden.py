@@ -470,7 +470,7 @@ def g17():
 
 
 # ---------------------------------------------------------------- G9 three-field trajectories
-def run_ref_3f(N, nu0, BCs, a_turb, a_prof, tol, maxit, inner=0, dt=1e6, keep=()):
+def run_ref_3f(N, nu0, BCs, a_turb, a_prof, tol, maxit, inner=0, dt=1e6, keep=(), ic=None, **solver_kw):
     dx = 1 / (N - 1); x = np.arange(N) * dx
     th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
 
@@ -502,7 +502,7 @@ def run_ref_3f(N, nu0, BCs, a_turb, a_prof, tol, maxit, inner=0, dt=1e6, keep=()
             nu = nu_of(profiles)
             return multifield.HCoefficients(H1=np.ones_like(xx), H6=-nu, H7=self.S, H8=nu) + HT
 
-    ic = 1 - 0.5 * x
+    ic = (1 - 0.5 * x) if ic is None else ic
     lms = [lodestro_method.lm(a_turb, a_prof, th) for _ in range(3)]
     f0 = multifield.Field(label='n', rightBC=BCs[0], profile_mminus1=1.0 * ic, compute_all_H=Hn(), lodestroMethod=lms[0])
     f1 = multifield.Field(label='pi', rightBC=BCs[1], profile_mminus1=1.0 * ic, compute_all_H=Hp(src(1, 0.1)),
@@ -513,7 +513,7 @@ def run_ref_3f(N, nu0, BCs, a_turb, a_prof, tol, maxit, inner=0, dt=1e6, keep=()
     multifield.check_fields_initialize(fields)
     call = multifield.ComputeAllHAllFields(fields, lodestro_method.TurbulenceHandler(dx, x, Flux3()))
     s = tsolver.Solver(1, x, np.array([0, dt]), maxit, tol, call, fields,
-                       useInnerIteration=inner > 0, innerIterationMaxCount=max(inner, 1))
+                       useInnerIteration=inner > 0, innerIterationMaxCount=max(inner, 1), **solver_kw)
     s.m += 1; s.converged = False; (s.t, s.dt) = s._get_tdt(s.tArray, s.m)
     s.errHistory[:] = 0
     s.profilesAllIterations = {l: np.zeros((maxit, N)) for l in ('n', 'pi', 'pe')}
@@ -547,6 +547,27 @@ def g9():
     save('g9_threefield', **out)
 
 
+def g18():
+    """Pseudo-timestep control on the three-field problem (tango/solver.py:198-216, :311-372 with three fields: a step is
+    redone with a halved pseudo-timestep when ANY of the three profiles moved too far): the example's setup from a steeper
+    start so that the control acts; every iterate of the first 30 is kept."""
+    N = 500
+    x = np.arange(N) * (1 / (N - 1))
+    ic = 1.6 - 1.2 * x
+    out = dict(N=N, nu0=2.2, bc=np.array((2.0, 0.1, 0.3)), ic=ic)
+    cases = {'lightly': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.2}),
+             'lightly_tight': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.05, 'innerFraction': 0.8}),
+             'initially': dict(useTreadInitially=True, treadInitiallyParams={'numInitialSteps': 6, 'dtau': 0.05}),
+             'both': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.1},
+                          useTreadInitially=True, treadInitiallyParams={'numInitialSteps': 4, 'dtau': 0.1})}
+    for tag, kw in cases.items():
+        fin, k, err, snaps, ew, conv = run_ref_3f(N, 2.2, (2, 0.1, 0.3), 0.3, 0.3, 1e-9, 400, keep=tuple(range(30)), ic=ic, **kw)
+        out.update({f'{tag}_iters': k, f'{tag}_err': err, f'{tag}_conv': conv, f'{tag}_n': fin[0], f'{tag}_pi': fin[1], f'{tag}_pe': fin[2],
+                    f'{tag}_first30': np.stack([np.stack(snaps[i]) for i in sorted(snaps)]), f'{tag}_ewma_pi': ew[1]})
+        print(tag, 'iterations', k, 'converged', conv)
+    save('g18_threefield_tread', **out)
+
+
 # ---------------------------------------------------------------- G11 residual, uncoupled
 def g11():
     rng = np.random.default_rng(11)
@@ -560,6 +581,6 @@ def g11():
 
 
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17']
+    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18']
     for w in which:
         globals()[w]()

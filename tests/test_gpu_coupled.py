@@ -169,6 +169,59 @@ def test_threefield_interrupt_and_continue(tango, nb):
     assert np.allclose(cont.errHistoryFinal, whole.errHistoryFinal[..., 9:20], rtol=1e-9, atol=1e-15)
 
 
+TREAD3_CASES = {'lightly': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.2}),
+                'lightly_tight': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.05, 'innerFraction': 0.8}),
+                'initially': dict(useTreadInitially=True, treadInitiallyParams={'numInitialSteps': 6, 'dtau': 0.05}),
+                'both': dict(useTreadLightly=True, treadLightlyParams={'maxFractionalChange': 0.1},
+                             useTreadInitially=True, treadInitiallyParams={'numInitialSteps': 4, 'dtau': 0.1})}
+
+
+@pytest.mark.parametrize('tag', sorted(TREAD3_CASES))
+@pytest.mark.parametrize('fused', [True, False])
+def test_threefield_pseudo_timestep_control(tango, golden, tag, fused):
+    """useTreadLightly / useTreadInitially on the three-field problem (tango/solver.py:198-216, :311-372): inside the fused
+    kernel and on the generic path, against the reference's own runs (g18: every one of the first 30 iterates)."""
+    g = golden('g18_threefield_tread')
+    N = int(g['N'])
+    maxit = 400 if fused else 30
+    s, lms = make_3f_solver(tango, N, float(g['nu0']), tuple(g['bc']), ic=g['ic'], fused=fused, maxit=maxit, **TREAD3_CASES[tag])
+    assert (s._fused is not None) == fused
+    s.take_timestep()
+    k = int(g[f'{tag}_iters'])
+    m = min(k, len(s.errHistoryFinal))
+    assert np.allclose(s.errHistoryFinal[:m], g[f'{tag}_err'][:m], rtol=1e-6, atol=5e-12)
+    for q, lab in enumerate(('n', 'pi', 'pe')):
+        assert relerr(s.profilesAllIterations[lab][:30], g[f'{tag}_first30'][:, q]) < TOL, lab
+    if fused:
+        assert s.converged and len(s.errHistoryFinal) == k
+        for lab in ('n', 'pi', 'pe'):
+            assert relerr(s.profiles[lab], g[f'{tag}_{lab}']) < TOL
+        assert relerr(lms[1]._EWMATurbD._yEWMA_lminus1, g[f'{tag}_ewma_pi'][0]) < TOL
+
+
+def test_threefield_pseudo_timestep_control_ensemble(tango):
+    """Per-profile halving inside one launch: an ensemble whose members need different numbers of halvings (several of
+    them share a wavefront at N = 64), each against the oracle run alone."""
+    for N, nb in ((64, 9), (512, 4)):
+        ens = orc.threefield_ensemble(nb, N)
+        nu0, bc = ens['nu0'], ens['bc']
+        ic = (1.2 + 0.5 * np.arange(nb)[:, None] / nb) - (0.8 + 0.4 * np.arange(nb)[:, None] / nb) * ens['x'][None, :]
+        tl = {'maxFractionalChange': 0.1}
+        s, _ = make_3f_solver(tango, N, nu0, tuple(bc[:, k].copy() for k in range(3)), ic=ic, maxit=25, tol=1e-30, useTreadLightly=True,
+                              treadLightlyParams=tl, iterationsPerCheck=5)
+        assert s._fused is not None and s.batched
+        s.take_timestep()
+        halved = 0
+        for b in range(nb):
+            (n, pi, pe), it, err, hist, halv = orc.run_3f_tread(ic[b], ic[b], ic[b], 1e6, ens['dx'], tuple(bc[b]), nu0[b], ens['x'], 0.3, 0.3,
+                                                                1e-30, 25, tread_lightly=tl)
+            halved += int(halv.max() > 0)
+            for lab, ref in (('n', n), ('pi', pi), ('pe', pe)):
+                assert relerr(s.profiles[lab][b], ref) < TOL, (N, b, lab)
+            assert np.allclose(s.errHistory[b, :25], err, rtol=1e-6, atol=5e-12)
+        assert halved >= 2
+
+
 def test_threefield_generic_path(tango, golden):
     """User-style callbacks: n through the scalar kernels, (pi, pe) through JK_to_matrix + the pair solve."""
     g = golden('g9_threefield')

@@ -283,3 +283,26 @@ def test_g17_grid_mapping_more(golden):
     assert relerr(orc.constrained_regression_line(g['xTi'], g['profi'], np.linspace(-0.2, 0.1, 7), 'left', 6), g['reg_left']) < 1e-13
     assert relerr(orc.truncate_on_left_extrapolate_on_right(g['xTi'], g['profi'], np.linspace(-0.2, 0.5, 23), 6, False, 'left'),
                   g['ext_left']) < 1e-13
+
+
+TREAD3_CASES = {'lightly': (dict(maxFractionalChange=0.2), None),
+                'lightly_tight': (dict(maxFractionalChange=0.05, innerFraction=0.8), None),
+                'initially': (None, dict(numInitialSteps=6, dtau=0.05)),
+                'both': (dict(maxFractionalChange=0.1), dict(numInitialSteps=4, dtau=0.1))}
+
+
+@pytest.mark.parametrize('tag', sorted(TREAD3_CASES))
+def test_threefield_pseudo_timestep_control_g18(golden, tag):
+    """The three-field restatement with tread-lightly / tread-initially against the reference's own runs."""
+    g = golden('g18_threefield_tread')
+    N = int(g['N']); dx = 1 / (N - 1); x = np.arange(N) * dx
+    tl, ti = TREAD3_CASES[tag]
+    (n, pi, pe), it, err, hist, halv = orc.run_3f_tread(g['ic'], g['ic'], g['ic'], 1e6, dx, tuple(g['bc']), float(g['nu0']), x, 0.3, 0.3,
+                                                        1e-9, 400, tread_lightly=tl, tread_initially=ti)
+    assert it == int(g[f'{tag}_iters'])
+    if tl is not None:
+        assert halv.max() >= 1           # the control acted
+    assert np.allclose(err, g[f'{tag}_err'], rtol=1e-7, atol=1e-13)
+    assert np.allclose(hist[:30], g[f'{tag}_first30'], rtol=1e-11, atol=0)
+    for got, key in ((n, 'n'), (pi, 'pi'), (pe, 'pe')):
+        assert np.allclose(got, g[f'{tag}_{key}'], rtol=1e-11, atol=0)
