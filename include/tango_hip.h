@@ -276,6 +276,10 @@ int tg_picard_1f_step_static(const tg_state_1f *state, const tg_params_1f *param
  * (tango/solver.py:404-418: the `ok` property of a whole ensemble). */
 int tg_status_reduce(const int32_t *status, int64_t nb, int64_t *counts, tg_stream stream);
 
+/* status[b] |= bits for every profile (e.g. TG_ST_SEEDED after the first pass of a pipeline that keeps the EWMA memories
+ * outside the fused step: tango/lodestro_method.py:706-708). */
+int tg_status_or(int32_t *status, int64_t nb, int32_t bits, tg_stream stream);
+
 /* Residual summary of an ensemble, the quantity tango/solver.py:464-475 (check_convergence) forms for one run, taken
  * over every profile that still iterates: out[0..4] (device doubles, zeroed by the call) = sum of squared normalised
  * residuals (n x rms^2 of each such profile's latest history entry), number of residual entries behind that sum,

@@ -111,6 +111,7 @@ PROTOTYPES = {
     'tg_picard_1f_step': (_int, [C.POINTER(State1F), C.POINTER(Params1F), _p]),
     'tg_picard_1f_step_static': (_int, [C.POINTER(State1F), C.POINTER(Params1F), _p]),
     'tg_status_reduce': (_int, [_p, _i64, _p, _p]),
+    'tg_status_or': (_int, [_p, _i64, C.c_int32, _p]),
     'tg_residual_reduce': (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p]),
     'tg_picard_3f_step': (_int, [C.POINTER(State3F), C.POINTER(Params3F), _p]),
 }

@@ -635,6 +635,11 @@ ar1_noise_kernel(uint64_t seed, uint64_t sequence, double amplitude, double lamb
     }
 }
 
+__global__ void status_or_kernel(int32_t *__restrict__ status, int64_t nb, int bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb) status[i] |= bits;
+}
+
 __global__ void status_reduce_kernel(const int32_t *__restrict__ status, int64_t nb, unsigned long long *counts) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1625,6 +1630,13 @@ int tg_status_reduce(const int32_t *status, int64_t nb, int64_t *counts, tg_stre
     if (nb == 0) return TG_OK;
     hipLaunchKernelGGL(status_reduce_kernel, dim3(grid_1d(nb, 256)), dim3(256), 0, S(stream), status, nb,
                        reinterpret_cast<unsigned long long *>(counts));
+    return launch_check();
+}
+
+int tg_status_or(int32_t *status, int64_t nb, int32_t bits, tg_stream stream) {
+    if (!status || nb < 0) return fail(TG_ERR_ARG, "bad argument%s");
+    if (nb == 0) return TG_OK;
+    hipLaunchKernelGGL(status_or_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, S(stream), status, nb, (int)bits);
     return launch_check();
 }
 

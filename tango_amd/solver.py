@@ -397,6 +397,8 @@ def _plan_fused(s):
     th = call.turbhandler
     if call.fields is not s.fields and list(call.fields) != list(s.fields):
         return None
+    if len(s.fields) == 1 and type(s.fields[0].gridMapper) is not _mf.GridsNull:
+        return _FusedMapped1F.plan(s)      # a turbulence grid of its own: the device-resident pipeline, or the generic path
     for f in s.fields:
         m = f.lodestroMethod
         if type(f.gridMapper) is not _mf.GridsNull or type(m) is not _lm.lm:
@@ -658,6 +660,8 @@ class _FusedExternal1F(_Fused1F):
     Needs a compute_all_H callback marked `static_H = True`: its own H coefficients (H1 and optionally H7) depend on x
     only, so they are evaluated once."""
 
+    _turb_on_transport_grid = True      # the flux model, the split and the EWMA memories live on the transport grid
+
     @classmethod
     def plan(cls, s):
         f = s.fields[0]
@@ -684,7 +688,7 @@ class _FusedExternal1F(_Fused1F):
         self.S0 = self.src_cut = None
         self.uE_host = None
         m = f.lodestroMethod
-        if m._EWMAProfile._yEWMA_lminus1 is not None:
+        if self._turb_on_transport_grid and m._EWMAProfile._yEWMA_lminus1 is not None:
             self.uE_host = np.atleast_2d(np.array(m._EWMAProfile._yEWMA_lminus1, dtype=np.float64))
             self.uE.set(self.uE_host)
             self.DE.set(np.atleast_2d(m._EWMATurbD._yEWMA_lminus1))
@@ -711,8 +715,10 @@ class _FusedExternal1F(_Fused1F):
         self.Vprime = self.gxx = self.gradx = None
         if th.isNonCartesian:
             self.Vprime, self.gxx, self.gradx = grid_array(th.VprimeTango), grid_array(th.gxxAvgTango), grid_array(th.gradxAvgTango)
-        self.gxx_turb = grid_array(sp.gxxAvg) if (np.ndim(sp.gxxAvg) or sp.gxxAvg != 1) else None
-        self.gradx_turb = grid_array(sp.gradxAvg) if (np.ndim(sp.gradxAvg) or sp.gradxAvg != 1) else None
+        self.gxx_turb = self.gradx_turb = None
+        if self._turb_on_transport_grid:
+            self.gxx_turb = grid_array(sp.gxxAvg) if (np.ndim(sp.gxxAvg) or sp.gxxAvg != 1) else None
+            self.gradx_turb = grid_array(sp.gradxAvg) if (np.ndim(sp.gradxAvg) or sp.gradxAvg != 1) else None
 
     def _verify_static(self, s):
         """A callback that was found static by trial calls only (no static_H attribute) is called again at every convergence
@@ -838,3 +844,166 @@ class _FusedExternal1F(_Fused1F):
             self.finish(s)
         finally:
             H.set_stream(previous)
+
+
+class _FusedMapped1F(_FusedExternal1F):
+    """One field whose turbulence lives on a grid of its own (gridMapper = interfacegrids_gene.GridInterfaceTangoOutside: the
+    transport grid reaches beyond the turbulence grid at both ends).  Every step of tango/lodestro_method.py:327-388 stays
+    on the device: spline of the profile onto the turbulence grid (tg_spline_resample), its EWMA (tg_ewma_profiles), the
+    flux model (built-in Shestakov flux, a model on the GPU, or a Python model on the host through page-locked buffers),
+    smoothing (tg_moving_average), the split (tg_flux_split), the EWMA of D and c on the turbulence grid, the spline of
+    both back onto the transport grid with zeros outside the turbulence grid, and the fused step with those coefficients
+    (tg_picard_1f_step, frozen_turb: assembly, residual, solve, validity check).  The EWMA memories live on the
+    turbulence grid, as in the reference."""
+
+    _turb_on_transport_grid = False
+
+    @classmethod
+    def plan(cls, s):
+        from . import interfacegrids_gene as _ig
+        f = s.fields[0]
+        th = s.compute_all_H_all_fields.turbhandler
+        m = f.lodestroMethod
+        if type(f.gridMapper) is not _ig.GridInterfaceTangoOutside or type(m) is not _lm.lm:
+            return None
+        if m._fluxSplitter.ftheta != m._fluxSplitter._default_ftheta or f.coupledTo is not None:
+            return None
+        if s.useInnerIteration or s.useTreadLightly or s.useTreadInitially:
+            return None
+        if not _callback_is_static(s):
+            return None
+        xg = np.asarray(f.gridMapper.get_x_turbulence_grid(), dtype=np.float64)
+        if xg.size < 4 or np.shape(s.x)[-1] < 4 or not np.array_equal(np.asarray(f.gridMapper.get_x_transport_grid()), np.asarray(s.x)):
+            return None
+        if abs((xg[1] - xg[0]) - th.dxTurbGrid) > 1e-12 * abs(th.dxTurbGrid):
+            return None
+        Hs = f.compute_all_H(s.tArray[0], s.x, dict(s.profiles), _mf.HCoefficients())
+        if Hs.H1 is None or any(getattr(Hs, k) is not None for k in ('H2', 'H3', 'H4', 'H6', 'H8')):
+            return None
+        return cls(s, Hs)
+
+    def __init__(self, s, Hs):
+        _FusedExternal1F.__init__(self, s, Hs)
+        f = s.fields[0]
+        D = H.DeviceArray
+        xT = np.ascontiguousarray(s.x, dtype=np.float64)
+        xG = np.ascontiguousarray(f.gridMapper.get_x_turbulence_grid(), dtype=np.float64)
+        self.nt = nt = xG.size
+        self.xT, self.xG = D.from_host(xT), D.from_host(xG)
+        # coefficients come back onto the transport points strictly inside the turbulence grid, zero elsewhere
+        # (tango/interfacegrids_gene.py:446-484)
+        self.lo = int(np.where(xT > xG[0])[0][0])
+        self.hi = int(np.where(xT < xG[-1])[0][-1]) + 1
+        from .ensemble import device_arrays
+        self.pT, self.uE_t, self.flux_t, self.D_t, self.c_t, self.DE_t, self.cE_t = device_arrays([((self.nb, nt), np.float64)] * 7, zero=True)
+        wb = max(int(H.lib.tg_spline_work_bytes(self.nb, self.n)), int(H.lib.tg_spline_work_bytes(self.nb, nt)))
+        self.spline_work = D((wb // 8,))
+        sp = f.lodestroMethod._fluxSplitter
+        arr = lambda v: D.from_host(np.broadcast_to(np.asarray(v, dtype=np.float64), (nt,)).copy())
+        self.gxx_t = arr(sp.gxxAvg) if (np.ndim(sp.gxxAvg) or sp.gxxAvg != 1) else None
+        self.gradx_t = arr(sp.gradxAvg) if (np.ndim(sp.gradxAvg) or sp.gradxAvg != 1) else None
+        self.gxx_turb = self.gradx_turb = None      # the split runs on the turbulence grid, outside the step kernel
+        m = f.lodestroMethod
+        if m._EWMAProfile._yEWMA_lminus1 is not None:      # restart: memories on the turbulence grid
+            self.uE_t.set(np.atleast_2d(m._EWMAProfile._yEWMA_lminus1))
+            self.DE_t.set(np.atleast_2d(m._EWMATurbD._yEWMA_lminus1))
+            self.cE_t.set(np.atleast_2d(m._EWMATurbc._yEWMA_lminus1))
+        self.seeded = m._EWMAProfile._yEWMA_lminus1 is not None
+
+    def params(self, s):
+        q = _FusedExternal1F.params(self, s)
+        q.flux_model, q.flux, q.smooth_window = H.FLUX_SHESTAKOV, None, 1      # the step gets D and c ready-made
+        q.frozen_turb, q.iters_per_launch = 1, 1
+        return q
+
+    def _resample(self, xin, yin, nin, xout, nout, lo, hi, nonneg, out):
+        H.check(H.lib.tg_spline_resample(xin.ptr, yin.ptr, self.nb, nin, xout.ptr, nout, lo, hi, int(nonneg), out.ptr,
+                                         self.spline_work.ptr, self.spline_work.nbytes, H.stream()))
+
+    def run_timestep(self, s):
+        q = self.params(s)
+        th = s.compute_all_H_all_fields.turbhandler
+        f = s.fields[0]
+        m = f.lodestroMethod
+        a_turb, a_prof = m.get_ewma_params()
+        tp = m._fluxSplitter.thetaParams
+        if s.m > 1:
+            self.um1.copy_from(self.u)
+            self.status.set((self.status.to_host() & H.ST_SEEDED).astype(np.int32))
+            H.check(H.lib.tg_memset(self.iters.ptr, 0, self.iters.nbytes, H.stream()))
+            H.check(H.lib.tg_memset(self.err.ptr, 0, self.err.nbytes, H.stream()))
+        if self.seeded:
+            H.check(H.lib.tg_status_or(self.status.ptr, self.nb, H.ST_SEEDED, H.stream()))
+        done = self.start = s.iterationNumber
+        hist = s.profilesAllIterations
+        pick = (lambda a: a) if s.batched else (lambda a: a[0])
+        model = th.fluxModel
+        builtin = getattr(model, 'fused_flux_model', None) == 'shestakov' and model.dx == th.dxTurbGrid
+        on_device = getattr(model, 'device_flux', False)
+        window = int(th.fluxSmoother.windowSize) if (th.doSmoothing and type(th.fluxSmoother) is _smoother.Smoother) else 1
+        host_smoothing = th.doSmoothing and window <= 1
+        if on_device:
+            import torch
+            dev = torch.device('cuda', torch.cuda.current_device())
+            uE_view, fl_view = _torch_view(self.uE_t, dev), _torch_view(self.flux_t, dev)
+            previous = H.stream()
+            H.set_stream(torch.cuda.current_stream().cuda_stream)
+        elif not builtin and getattr(self, '_pinned_t', None) is None:
+            self._pinned_t = (H.PinnedArray((self.nb, self.nt)), H.PinnedArray((self.nb, self.nt)))
+        try:
+            while done < s.maxIterations:
+                if (done - self.start) % s.iterationsPerCheck == 0:
+                    H.check(H.lib.tg_status_reduce(self.status.ptr, self.nb, self.counts.ptr, H.stream()))
+                    if int(self.counts.to_host()[0]) == 0:
+                        break
+                    self._verify_static(s)
+                # profile onto the turbulence grid and its EWMA there (tango/lodestro_method.py:344-345)
+                self._resample(self.xT, self.u, self.n, self.xG, self.nt, 0, self.nt, False, self.pT)
+                H.check(H.lib.tg_ewma_profiles(self.pT.ptr, self.uE_t.ptr, float(a_prof), self.status.ptr, self.nb, self.nt, H.stream()))
+                # flux on the turbulence grid (:350), smoothing (:359-362)
+                if builtin:
+                    H.check(H.lib.tg_shestakov_flux(self.uE_t.ptr, float(th.dxTurbGrid), self.flux_t.ptr, self.nb, self.nt, H.stream()))
+                    flux_dev = self.flux_t
+                elif on_device:
+                    flux = model.get_flux({self.label: uE_view if s.batched else uE_view[0]})[self.label]
+                    fl_view.copy_(torch.as_tensor(flux, device=dev).reshape(self.nb, self.nt))
+                    flux_dev = self.flux_t
+                else:
+                    uE_pin, fl_pin = self._pinned_t
+                    flux = np.asarray(model.get_flux({self.label: pick(uE_pin.download(self.uE_t))})[self.label], dtype=np.float64)
+                    if host_smoothing:
+                        flux = np.asarray(th.fluxSmoother.smooth(flux), dtype=np.float64)
+                    fl_pin.array[...] = np.atleast_2d(flux)
+                    fl_pin.upload(self.flux_t)
+                    flux_dev = self.flux_t
+                if window > 1:
+                    H.check(H.lib.tg_moving_average(flux_dev.ptr, window, self.D_t.ptr, self.nb, self.nt, H.stream()))
+                    H.check(H.lib.tg_copy_d2d(self.flux_t.ptr, self.D_t.ptr, self.flux_t.nbytes, H.stream()))
+                # split and EWMA of D and c on the turbulence grid (:365-369)
+                H.check(H.lib.tg_flux_split(self.flux_t.ptr, self.uE_t.ptr, float(th.dxTurbGrid), float(tp['Dmin']), float(tp['Dmax']),
+                                            float(tp['dpdxThreshold']), H.ptr_of(self.gxx_t), H.ptr_of(self.gradx_t), self.D_t.ptr,
+                                            self.c_t.ptr, None, None, None, self.nb, self.nt, H.stream()))
+                H.check(H.lib.tg_ewma_profiles(self.D_t.ptr, self.DE_t.ptr, float(a_turb), self.status.ptr, self.nb, self.nt, H.stream()))
+                H.check(H.lib.tg_ewma_profiles(self.c_t.ptr, self.cE_t.ptr, float(a_turb), self.status.ptr, self.nb, self.nt, H.stream()))
+                # back onto the transport grid (:372), D kept non-negative (tango/interfacegrids_gene.py:59-64)
+                self._resample(self.xG, self.DE_t, self.nt, self.xT, self.n, self.lo, self.hi, True, self.DE)
+                self._resample(self.xG, self.cE_t, self.nt, self.xT, self.n, self.lo, self.hi, False, self.cE)
+                if not self.seeded:
+                    H.check(H.lib.tg_status_or(self.status.ptr, self.nb, H.ST_SEEDED, H.stream()))
+                    self.seeded = True
+                H.check(H.lib.tg_picard_1f_step(C.byref(self.state), C.byref(q), H.stream()))
+                done += 1
+                if hist is not None:
+                    hist[self.label][done - 1 - self.start] = pick(self.u.to_host())
+        finally:
+            if on_device:
+                H.set_stream(previous)
+        self.finish(s)
+
+    def finish(self, s):
+        keep = (self.uE, self.DE, self.cE)
+        self.uE, self.DE, self.cE = self.uE_t, self.DE_t, self.cE_t      # the memories the caller sees live on the turbulence grid
+        try:
+            _Fused1F.finish(self, s)
+        finally:
+            self.uE, self.DE, self.cE = keep

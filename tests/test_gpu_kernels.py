@@ -225,27 +225,74 @@ def test_grid_mapping_golden(tango, golden):
     assert relerr(D2[0], g['ext_D_on_T']) < 1e-11 and relerr(c2[1], -g['ext_c_on_T']) < 1e-11
 
 
-def test_solver_with_grid_mapper(tango, golden):
-    """A one-field run whose flux model lives on a finer, shorter turbulence grid (generic path: every map is a
-    kernel call), against the reference's trajectory."""
+@pytest.mark.parametrize('path', ['pipeline', 'pipeline, python flux model', 'generic'])
+def test_solver_with_grid_mapper(tango, golden, path):
+    """A one-field run whose flux model lives on a finer, shorter turbulence grid, against the reference's trajectory:
+    the device-resident pipeline (resampling, EWMA, flux, split and the fused step with no host array in between; with
+    the packaged flux model and with a Python flux model called on the host) and the generic path (every map a kernel
+    call, host arrays in between)."""
     g = golden('g16_gridmap')
     N, NG = int(g['run_N']), int(g['run_NG'])
     x = np.linspace(0, 1, N)
     xg = np.linspace(0.1, 0.9, NG); dxg = xg[1] - xg[0]
     sh = tango.extras.shestakov_nonlinear_diffusion
     lm = tango.lodestro_method.lm(0.3, 1.0, {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10})
-    f = tango.multifield.Field(label='n', rightBC=0.05, profile_mminus1=1 - 0.5 * x, compute_all_H=sh.ComputeAllH(1.0, 0.3),
+    cb = sh.ComputeAllH(1.0, 0.3)
+    if path == 'generic':
+        cb = (lambda inner: (lambda t, xx, p, HT: inner(t, xx, p, HT)))(cb)        # a plain callable: no static_H attribute
+
+    class PythonFlux(object):
+        def get_flux(self, profiles):
+            return {'n': np.asarray(sh.get_flux(profiles['n'], dxg))}
+    model = PythonFlux() if 'python' in path else sh.AnalyticFluxModel(dxg)
+    f = tango.multifield.Field(label='n', rightBC=0.05, profile_mminus1=1 - 0.5 * x, compute_all_H=cb,
                                gridMapper=tango.interfacegrids_gene.GridInterfaceTangoOutside(x, xg), lodestroMethod=lm)
     tango.multifield.check_fields_initialize([f])
-    call = tango.multifield.ComputeAllHAllFields([f], tango.lodestro_method.TurbulenceHandler(dxg, x, sh.AnalyticFluxModel(dxg)))
-    s = tango.solver.Solver(1, x, np.array([0, 0.5]), 25, 1e-14, call, [f])
-    assert s._fused is None
+    call = tango.multifield.ComputeAllHAllFields([f], tango.lodestro_method.TurbulenceHandler(dxg, x, model))
+    s = tango.solver.Solver(1, x, np.array([0, 0.5]), 25, 1e-14, call, [f], detectStaticH=False, iterationsPerCheck=4)
+    assert (type(s._fused).__name__ == '_FusedMapped1F') == (path != 'generic') and (s._fused is None) == (path == 'generic')
     s.take_timestep()
     assert len(s.errHistoryFinal) == 25
     assert np.allclose(s.errHistoryFinal, g['run_err'], rtol=1e-7, atol=1e-13)
     assert relerr(s.profilesAllIterations['n'][2], g['run_it2']) < 1e-10
     assert relerr(s.profiles['n'], g['run_final']) < 1e-10
     assert relerr(lm._EWMATurbD._yEWMA_lminus1, g['run_DE']) < 1e-10
+
+
+def test_grid_mapper_pipeline_ensemble(tango):
+    """The device-resident mapped pipeline on an ensemble whose members stop on their own iterations, member by member against
+    the same run on the generic path (same kernels for every map, host arrays in between)."""
+    N, NG, nb = 96, 200, 5
+    x = np.linspace(0, 1, N)
+    xg = np.linspace(0.12, 0.88, NG); dxg = xg[1] - xg[0]
+    sh = tango.extras.shestakov_nonlinear_diffusion
+    S0 = np.linspace(0.8, 1.2, nb); nL = np.linspace(0.04, 0.06, nb)
+    u0 = np.linspace(0.9, 1.1, nb)[:, None] * (1 - 0.5 * x)[None, :]
+    # with the flux smoothed over 5 points this problem stops contracting after a few iterations (in the reference too: its
+    # residuals 15.7, 1.72, ... are the ones found here), so that case is compared over its first four iterations
+    for window, iterations in ((None, 25), (5, 4)):
+        res = []
+        for generic in (False, True):
+            lm = tango.lodestro_method.lm(0.3, 1.0, {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10})
+            cb = sh.ComputeAllH(S0, 0.3)
+            if generic:
+                cb = (lambda inner: (lambda t, xx, p, HT: inner(t, xx, p, HT)))(cb)
+            f = tango.multifield.Field(label='n', rightBC=nL, profile_mminus1=u0, compute_all_H=cb,
+                                       gridMapper=tango.interfacegrids_gene.GridInterfaceTangoOutside(x, xg), lodestroMethod=lm)
+            tango.multifield.check_fields_initialize([f])
+            handler = tango.lodestro_method.TurbulenceHandler(dxg, x, sh.AnalyticFluxModel(dxg),
+                                                              fluxSmoother=tango.smoother.Smoother(window) if window else None)
+            call = tango.multifield.ComputeAllHAllFields([f], handler)
+            s = tango.solver.Solver(1, x, np.array([0, 0.5]), iterations, 1e-30, call, [f], detectStaticH=False, iterationsPerCheck=7)
+            assert (s._fused is None) == generic
+            s.take_timestep()
+            err = np.array(s.errHistory)
+            res.append((np.array(s.profiles['n']), err if generic else err.max(axis=0), np.array(lm._EWMATurbc._yEWMA_lminus1),
+                        np.array(lm._EWMATurbD._yEWMA_lminus1)))
+        if window:
+            assert relerr(res[1][1][1:3], [15.7179152, 1.71811159]) < 1e-8      # the reference's own residuals
+        for a, b in zip(res[0], res[1]):
+            assert a.shape == b.shape and relerr(a, b) < 2e-9
 
 
 def test_grid_mapping_more_golden(tango, golden):
