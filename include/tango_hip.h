@@ -216,7 +216,11 @@ typedef struct {
     int32_t fixed_count;   /* nonzero: step every profile regardless of its status, never mark converged */
     int32_t frozen_turb;   /* nonzero: reuse DE,cE as they are (inner iteration, tango/solver.py:274-309) */
     int32_t iters_per_launch; /* <= 1: one iteration per call; k > 1: up to k iterations per call with the profile
-                                 held in registers in between (each profile still stops on its own iteration) */
+                                 held in registers in between (each profile still stops on its own iteration).  In the
+                                 segmented form (see work) the k iterations are a chain of kernels inside the call and
+                                 the results are those of k calls, with one exception: a profile that turns invalid
+                                 (TG_ST_INVALID) at an iteration before the last has its EWMA memories advanced once
+                                 more in the segments that did not see the invalid values */
     /* Pseudo-timestep control (tango/solver.py:198-216,233-235,311-372).  pseudo_time: the previous iterate takes
      * the u_{m-1} slot every iteration (useTreadLightly or useTreadInitially).  tread_initial_steps > 0: the first
      * that many iterations of a profile use tread_initial_dtau instead of dt.  tread_lightly: a new iterate whose
@@ -230,11 +234,12 @@ typedef struct {
     int32_t reserved_;     /* set to 0; used by the library */
     double tread_max_change;
     double tread_initial_dtau;
-    /* Optional work space of tg_picard_1f_work_bytes(nb, n) bytes.  With it, profiles of more than 4096 points
-     * (n a multiple of 512, built-in flux, Cartesian, one iteration per call) are stepped in segments of 512 points,
-     * one wavefront each, in three kernels: turbulence update + assembly + elimination per segment; the reduced
-     * system of the segment-lane unknowns per profile; back substitution per segment.  Without it (NULL) such
-     * profiles take the one-workgroup-per-profile kernel, which is 2-4 times slower at those sizes. */
+    /* Optional work space of tg_picard_1f_work_bytes(nb, n) bytes.  With it, profiles of n = 8192, 16384 or 32768
+     * points (built-in flux, Cartesian, no pseudo-timestep control) are stepped in segments of 512 points, one
+     * wavefront each, in three kernels: turbulence update + assembly + elimination per segment; the reduced system
+     * of the segment-lane unknowns per profile; back substitution per segment (with iters_per_launch > 1 the back
+     * substitution of one iteration and the first kernel of the next are one kernel).  Without it (NULL) such
+     * profiles take the one-workgroup-per-profile kernel (n <= 16384), which is 2-4 times slower at those sizes. */
     void *work;
     size_t work_bytes;
     /* Optional history of the iterates (profilesAllIterations of tango/solver.py:225-227): the profile that
@@ -261,15 +266,15 @@ int tg_picard_1f_step(const tg_state_1f *state, const tg_params_1f *params, tg_s
 
 /* The same step for callers that cannot allocate device memory (code under HIP graph capture, serving loops,
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  It is tg_picard_1f_step for the profile
- * lengths whose step needs a work space (n = 8192, 16384, 32768; built-in flux, Cartesian, one iteration per call),
+ * lengths whose step needs a work space (n = 8192, 16384, 32768; built-in flux, Cartesian),
  * with params->work ignored: the work space is a TG_STATIC_WORK_BYTES array inside the library, one per GPU, held
- * until the process ends.  tg_picard_1f_work_bytes(nb, n) must not exceed TG_STATIC_WORK_BYTES (about 4.4 million
+ * until the process ends.  tg_picard_1f_work_bytes(nb, n) must not exceed TG_STATIC_WORK_BYTES (about 4.7 million
  * grid points in all, e.g. 512 x 8192); larger ensembles get TG_ERR_ARG, other profile lengths TG_ERR_UNSUPPORTED
  * (they need no work space: tg_picard_1f_step allocates nothing for them either).  The call allocates and frees
  * nothing; the first call on a device looks up the array's address (make it outside graph capture).  All calls
  * on one GPU share that array: calls that overlap in time on one GPU (different streams or threads) race; calls
  * ordered on one stream are safe, every call clears what it needs cleared. */
-enum { TG_STATIC_WORK_BYTES = 36 * 1024 * 1024 };
+enum { TG_STATIC_WORK_BYTES = 24 * 1024 * 1024 };
 int tg_picard_1f_step_static(const tg_state_1f *state, const tg_params_1f *params, tg_stream stream);
 
 /* counts[0..3] (device int64, zeroed by the call): profiles still active, converged, invalid, singular

@@ -16,7 +16,7 @@ TG_OK, TG_ERR_ARG, TG_ERR_HIP, TG_ERR_UNSUPPORTED = 0, 1, 2, 3
 POINT_FASTEST, BATCH_FASTEST = 0, 1
 ST_CONVERGED, ST_INVALID, ST_SINGULAR, ST_SEEDED, ST_TREAD_LIMIT = 1, 2, 4, 8, 16
 FLUX_SHESTAKOV, FLUX_EXTERNAL, FLUX_POWER = 0, 1, 2
-STATIC_WORK_BYTES = 36 * 1024 * 1024
+STATIC_WORK_BYTES = 24 * 1024 * 1024
 
 
 class HipError(RuntimeError):

@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "../../include/tango_hip.h"
 #include "tg_assemble.h"
@@ -34,22 +35,27 @@ namespace {
 using namespace tg;
 
 constexpr int kSeg = 512;        // points per segment = 64 lanes x 8 points
-constexpr int kRowQ = 7;         // doubles a lane leaves for the reduced system
+constexpr int kRowQ = 4;         // doubles a lane leaves for the reduced system
+constexpr int kHaloQ = 12;       // doubles kept per segment boundary
 
 // work space layout (all double unless noted), L = nb n / 8 lanes, S = n / 512 segments per profile
 struct SegWork {
-    double *row[kRowQ];   // el, ll, fl, rl (last-row form), F, E, tau (first-row form), each (L,)
+    double *row[kRowQ];   // each (L,): the lane's row of the reduced system (sub-diagonal, super-diagonal, right-hand side,
+                          // slack); lane 63 of a segment, whose right neighbour belongs to another wavefront, leaves its
+                          // last-row form (e, l, f, rho) instead
+    double *first;        // (nb S, 3) first-row form (F, E, tau) of lane 0 of every segment, for lane 63 of the segment before
     double *y;            // (L,) lane-last unknowns
     double *ss, *mx;      // (nb S,) residual partial sums and max |f| per segment
-    double *halo;         // (nb (S-1), 8) EWMA memories at the four points around every segment boundary, copied before
-                          // phase 0 overwrites them: uE(j-2), uE(j-1), uE(j), uE(j+1), DE(j-1), DE(j), cE(j-1), cE(j), j = 512 (k+1)
-    int32_t *flag;        // (nb,) 0: not stepped in this call, 1: stepped, 2: stepped and converged
+    double *halo;         // (nb (S-1), 12) EWMA memories at the four points around every segment boundary, copied before a
+                          // first half overwrites them: uE(j-2), uE(j-1), uE(j), uE(j+1), DE(j-1), DE(j), cE(j-1), cE(j),
+                          // j = 512 (k+1); then, between two iterations of one call, the new profile at j-2 .. j+1
+    int32_t *flag;        // (nb,) 0: not stepped in this iteration, 1: stepped, 2: stepped and converged
     int32_t *sing;        // (nb,) zero pivot met somewhere
 };
 
 size_t seg_work_bytes(int64_t nb, int64_t n) {
     const int64_t L = nb * n / 8, S = n / kSeg;
-    size_t b = sizeof(double) * (size_t)((kRowQ + 1) * L + 2 * nb * S + 8 * nb * (S - 1)) + sizeof(int32_t) * (size_t)(2 * nb);
+    size_t b = sizeof(double) * (size_t)((kRowQ + 1) * L + 5 * nb * S + kHaloQ * nb * (S - 1)) + sizeof(int32_t) * (size_t)(2 * nb);
     return (b + 255) & ~(size_t)255;
 }
 
@@ -61,7 +67,8 @@ SegWork seg_carve(void *work, int64_t nb, int64_t n) {
     W.y = p; p += L;
     W.ss = p; p += nb * S;
     W.mx = p; p += nb * S;
-    W.halo = p; p += 8 * nb * (S - 1);
+    W.halo = p; p += kHaloQ * nb * (S - 1);
+    W.first = p; p += 3 * nb * S;
     W.flag = reinterpret_cast<int32_t *>(p);
     W.sing = W.flag + nb;
     return W;
@@ -75,16 +82,39 @@ __device__ __forceinline__ int64_t lane_slot(int64_t profile, int n, int r) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Phase 0 replaces uE, DE and cE in place while neighbouring segments still need the old values next to their
-// boundaries: those are copied aside first (one thread per boundary).
+// One row of a lane's sweep: face values of H2, H3 towards the next point, the row of tango/HToMatrixFD.py:87-117, the
+// carried face values moved on.  Shared by the segment kernels and the boundary kernel, which must round alike.
 // ------------------------------------------------------------------------------------------
-__global__ void seg_halo_kernel(tg_state_1f S_, SegWork W) {
+struct FaceCarry {
+    double hm2, hm3, bm, h2c, h3c;
+};
+
+__device__ __forceinline__ void seg_row(FaceCarry &c, double h2n, double h3n, bool last, double H1, double um1, const Recip &rc, double UL,
+                                        double h7, double &A, double &B, double &C, double &f) {
+    const double hp2 = (c.h2c + h2n) / 2.0;
+    const double hp3 = (c.h3c + h3n) / 2.0;
+    const double bp = fbeta_point<kDivRounded>(hp2, hp3, rc.dx);
+    fd_row<true>(last, H1, um1, rc, UL, c.hm2, c.hm3, c.bm, hp2, hp3, bp, 0.0, 0.0, h7, A, B, C, f);
+    c.hm2 = hp2;
+    c.hm3 = hp3;
+    c.bm = bp;
+    c.h2c = h2n;
+    c.h3c = h3n;
+}
+
+// One step of the back substitution inside a lane, x_i = (f_i - l_i y_left) - e_i x_{i+1}.
+__device__ __forceinline__ double back_step(double f, double l, double e, double y_left, double x_next) {
+    return fma(-e, x_next, fma(-l, y_left, f));
+}
+
+// ------------------------------------------------------------------------------------------
+// A first half replaces uE, DE and cE in place while neighbouring segments still need the old values next to their
+// boundaries: those are copied aside first.  Boundary k of profile b lies before point jb = 512 (k + 1).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void boundary_snapshot(const tg_state_1f &S_, const SegWork &W, int64_t b, int k) {
     const int S = (int)(S_.n / kSeg);
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= S_.nb * (S - 1)) return;
-    const int64_t b = k / (S - 1);
-    const int64_t j = b * S_.n + (int64_t)((k - b * (S - 1)) + 1) * kSeg;
-    double *h = W.halo + 8 * k;
+    const int64_t j = b * S_.n + (int64_t)(k + 1) * kSeg;
+    double *h = W.halo + kHaloQ * (b * (S - 1) + k);
     h[0] = S_.uE[j - 2];
     h[1] = S_.uE[j - 1];
     h[2] = S_.uE[j];
@@ -95,11 +125,80 @@ __global__ void seg_halo_kernel(tg_state_1f S_, SegWork W) {
     h[7] = S_.cE[j];
 }
 
+__global__ void seg_halo_kernel(tg_state_1f S_, SegWork W) {
+    const int S = (int)(S_.n / kSeg);
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S_.nb * (S - 1)) return;
+    const int64_t b = k / (S - 1);
+    boundary_snapshot(S_, W, b, (int)(k - b * (S - 1)));
+}
+
+// Between two iterations of one call, when the second half of the iteration and the first half of the next run in
+// one kernel, an edge lane also needs the neighbouring segment's NEW profile at the two points next to the boundary
+// before the neighbour has stored it.  One thread per side of a boundary redoes the sweep of the lane on its side
+// (rows 0..6, the same row function and elimination as the segment kernels) and its back substitution from the lane
+// unknowns y (indexed by lane within the profile), exactly as the owner of those rows will.
+// side 0: last lane of the segment on the left, 1: first lane of the segment on the right.
+__device__ __forceinline__ void boundary_next_profile(const tg_state_1f &S_, const tg_params_1f &Q, const SegWork &W, int64_t b, int k,
+                                                      int side, const double *y_of_lane) {
+    constexpr int P = 8;
+    const int S = (int)(S_.n / kSeg);
+    const int64_t off = b * S_.n;
+    const int jb = (k + 1) * kSeg;
+    double *h = W.halo + kHaloQ * (b * (S - 1) + k);
+    const int j0 = side ? jb : jb - P;            // the lane's first point
+    const int lane_r = j0 / P;
+    const Recip rc(Q.dx, Q.dt_b ? Q.dt_b[b] : Q.dt);
+    const double UL = Q.UL[b];
+    const double S0 = Q.H7 ? 0.0 : Q.S0[b];
+    const int src_cut = Q.H7 ? 0 : Q.src_cut[b];
+    const double *DEp = S_.DE + off, *cEp = S_.cE + off, *mp = S_.um1 + off;
+    ChunkElim<P, kDivRounded> el;
+    FaceCarry c;
+    c.hm2 = (DEp[j0 - 1] + DEp[j0]) / 2.0;
+    c.hm3 = (-cEp[j0 - 1] - cEp[j0]) / 2.0;
+    c.bm = fbeta_point<kDivRounded>(c.hm2, c.hm3, rc.dx);
+    c.h2c = DEp[j0];
+    c.h3c = -cEp[j0];
+#pragma unroll
+    for (int i = 0; i < P - 1; ++i) {
+        const int j = j0 + i;
+        const double H1 = Q.H1 ? Q.H1[j] : 1.0;
+        const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + j] : ((j < src_cut) ? S0 : 0.0);
+        double A, B, C, f;
+        seg_row(c, DEp[j + 1], -cEp[j + 1], false, H1, mp[j], rc, UL, h7, A, B, C, f);
+        el.push(i, C, B, A, f);
+    }
+    const double y = y_of_lane[lane_r];
+    const double yl = y_of_lane[lane_r - 1];
+    if (side == 0) {
+        h[9] = y;                                                       // u(jb-1)
+        h[8] = back_step(el.f[P - 2], el.l[P - 2], el.e[P - 2], yl, y);       // u(jb-2)
+    } else {
+        double xx = y, x1 = 0.0;
+#pragma unroll
+        for (int i = P - 2; i >= 0; --i) {
+            xx = back_step(el.f[i], el.l[i], el.e[i], yl, xx);
+            if (i == 1) x1 = xx;
+        }
+        h[10] = xx;                                                     // u(jb)
+        h[11] = x1;                                                     // u(jb+1)
+    }
+}
+
 // ------------------------------------------------------------------------------------------
-// phases 0 and 1: one wavefront per segment
+// the two halves of an iteration: one wavefront per segment
 // ------------------------------------------------------------------------------------------
+// PHASE 0: first half of an iteration (turbulence update, assembly, elimination down to the lanes' last unknowns).
+// PHASE 1: second half (assembly and elimination again, back substitution, new profile stored).
+// PHASE 2: the second half of one iteration and, for profiles that go on, the first half of the next in the same
+//          wavefront: D, c, u_{m-1} and the new profile are in registers already, so the next first half reads only the
+//          profile's EWMA memory (80 instead of 115 bytes per point and iteration).  The two points of the new profile
+//          that an edge lane needs from the neighbouring segment come from the reduce kernel (boundary_next_profile).
+// wavefronts per SIMD: three (<= 168 registers) and four (<= 128) for the two halves; the combined kernel needs 216
+// registers, and with them at two per SIMD it measured 17 % faster than with 168 and 48 of them spilled
 template <int PHASE>
-__global__ void __launch_bounds__(256, PHASE == 0 ? 3 : 4)      // three (four) wavefronts per SIMD: <= 168 (128) registers
+__global__ void __launch_bounds__(256, PHASE == 0 ? 3 : (PHASE == 1 ? 4 : 2))
 picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
     extern __shared__ double lds[];
     using G = WaveGroup<64>;
@@ -113,10 +212,12 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
     const int64_t b = w / S;
     const int s = (int)(w - b * S);
     const int st = S_.status[b];
+    int flag = 1;
     if (PHASE == 0) {
         if (!Q.fixed_count && (st & (TG_ST_CONVERGED | TG_ST_INVALID))) return;
     } else {
-        if (W.flag[b] == 0) return;
+        flag = W.flag[b];
+        if (flag == 0) return;
     }
     const int t = g.t();
     const int j0 = s * kSeg + t * P;                 // first point of this lane within the profile
@@ -132,11 +233,12 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
     const int src_cut = Q.H7 ? 0 : Q.src_cut[b];
     const Theta th(Q.Dmin, Q.Dmax, Q.dpdx_thr);
     const double omp = 1.0 - Q.a_prof, omt = 1.0 - Q.a_turb;
-    const bool seeded = (st & TG_ST_SEEDED) != 0;
     const bool turb = !Q.frozen_turb;
+    // the second half of the first iteration seeds the memories: a first half that follows it in this launch finds them seeded
+    const bool seeded = (st & TG_ST_SEEDED) != 0 || (PHASE == 2 && turb);
 
     using Tile = WaveTile<8>;
-    constexpr int NT = (PHASE == 0) ? 3 : 2;      // LDS tiles per wavefront: few enough for three wavefronts per SIMD
+    constexpr int NT = (PHASE == 1) ? 2 : 3;      // LDS tiles per wavefront: few enough for three wavefronts per SIMD
     Tile wt(lds + (threadIdx.x >> 6) * NT * Tile::kDoubles);
 
     double u[P + 2], um1[P], DE[P], cE[P];
@@ -145,41 +247,166 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
     const bool edge_l = (t == 0 && s > 0), edge_r = (t == 63 && s < S - 1);
     const int jh = edge_l ? j0 - 1 : j0 + P;         // the halo point of an edge lane
     double h_ue = 0.0, h_D = 0.0, h_c = 0.0, h_u = 0.0;
+    // the neighbouring segment's two nearest points, for the edge lanes of a first half: its new iterates are recomputed
+    // here (index 0: the halo point, 1: one further out); memories as they were before this launch's first half
+    double n_u0 = 0.0, n_u1 = 0.0, n_e0 = 0.0, n_e1 = 0.0, n_D = 0.0, n_c = 0.0;
+    auto snapshot = [&]() {
+        const double *h = W.halo + kHaloQ * (b * (S - 1) + (edge_l ? s - 1 : s));
+        n_e0 = edge_l ? h[1] : h[2];
+        n_e1 = edge_l ? h[0] : h[3];
+        n_D = edge_l ? h[4] : h[5];
+        n_c = edge_l ? h[6] : h[7];
+    };
 
-    if (PHASE == 0) {
-        double ue[P];
-        double2 r0[4], r1[4], r2[4], r3[4], r4[4];
-        wt.fetch(S_.u + woff, r0);
-        wt.fetch(S_.uE + woff, r1);
+    // assembly and elimination of this lane's rows (tango/HToMatrixFD.py:87-117 row by row, as in picard_1f_kernel);
+    // RESID: the residual of the current profile with the new matrix (tango/fieldgroups.py:139), zero-padded shifts at
+    // the two ends of the profile
+    auto assemble = [&](auto resid, ChunkElim<P, kDivRounded> &el, double &ss, double &mx) {
+        constexpr bool RESID = decltype(resid)::value;
+        // H2 = D, H3 = -c of the neighbouring lanes' nearest points; across a segment boundary the halo point's
+        // (every lane takes part in the shuffles; the edge lanes then substitute their halo values)
+        const double s2l = g.from_left(DE[P - 1], 1, 0.0), s3l = g.from_left(-cE[P - 1], 1, 0.0);
+        const double s2r = g.from_right(DE[0], 1, 0.0), s3r = g.from_right(-cE[0], 1, 0.0);
+        const double h2l = edge_l ? h_D : s2l;
+        const double h3l = edge_l ? -h_c : s3l;
+        const double h2r = edge_r ? h_D : s2r;
+        const double h3r = edge_r ? -h_c : s3r;
+        if constexpr (RESID) {
+            const double ul = g.from_left(u[P], 1, 0.0), ur = g.from_right(u[1], 1, 0.0);
+            u[0] = edge_l ? h_u : ul;
+            u[P + 1] = edge_r ? h_u : ur;
+        }
+        FaceCarry c;
+        c.hm2 = first_lane ? 0.0 : (h2l + DE[0]) / 2.0;
+        c.hm3 = first_lane ? 0.0 : (h3l - cE[0]) / 2.0;
+        c.bm = fbeta_point<kDivRounded>(c.hm2, c.hm3, rc.dx);
+        c.h2c = DE[0];
+        c.h3c = -cE[0];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int j = j0 + i;
+            const bool last = (i == P - 1) && last_lane;
+            const double h2n = (i == P - 1) ? h2r : DE[i < P - 1 ? i + 1 : 0];
+            const double h3n = (i == P - 1) ? h3r : -cE[i < P - 1 ? i + 1 : 0];
+            const double H1 = Q.H1 ? Q.H1[j] : 1.0;
+            const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + j] : ((j < src_cut) ? S0 : 0.0);
+            double A, B, C, f;
+            seg_row(c, h2n, h3n, last, H1, um1[i], rc, UL, h7, A, B, C, f);
+            if constexpr (RESID) {
+                const double r = A * u[i + 2] + B * u[i + 1] + C * u[i] - f;
+                ss += r * r;
+                mx = fmax(mx, fabs(f));
+            }
+            el.push(i, C, B, A, f);
+        }
+    };
+
+    if (PHASE != 0) {
+        // ---- second half of an iteration ----
+        double2 r1[4], r2[4], r3[4], r4[4];
         wt.fetch(S_.DE + woff, r2);
         wt.fetch(S_.cE + woff, r3);
         wt.fetch(S_.um1 + woff, r4);
-        // the neighbouring segment's two nearest points, for the edge lanes: its new iterates are recomputed here
-        double n_u0 = 0.0, n_u1 = 0.0, n_e0 = 0.0, n_e1 = 0.0, n_D = 0.0, n_c = 0.0;   // index 0: the halo point, 1: one further out
+        if (PHASE == 2) wt.fetch(S_.uE + woff, r1);
         if (edge_l || edge_r) {
-            const int j1 = edge_l ? jh - 1 : jh + 1;
-            n_u0 = S_.u[off + jh];       // u changes in phase 1 only
-            n_u1 = S_.u[off + j1];
-            const double *h = W.halo + 8 * (b * (S - 1) + (edge_l ? s - 1 : s));
-            n_e0 = edge_l ? h[1] : h[2];
-            n_e1 = edge_l ? h[0] : h[3];
-            n_D = edge_l ? h[4] : h[5];
-            n_c = edge_l ? h[6] : h[7];
+            if (PHASE == 2) {
+                // the neighbours may already be replacing their memories: the copies taken before this launch
+                snapshot();
+                h_D = n_D;
+                h_c = n_c;
+            } else {
+                h_D = S_.DE[off + jh];
+                h_c = S_.cE[off + jh];
+            }
         }
-        wt.stage(0, r0);
-        wt.stage(1, r1);
-        wt.stage(2, r2);
+        wt.stage(0, r2);
+        wt.stage(1, r3);
         Tile::sync();
-        wt.take(0, u + 1);
-        wt.take(1, ue);
-        wt.take(2, DE);
+        wt.take(0, DE);
+        wt.take(1, cE);
         Tile::sync();
-        wt.stage(0, r3);
-        wt.stage(1, r4);
+        wt.stage(0, r4);
+        if (PHASE == 2) wt.stage(2, r1);      // the profile's EWMA memory waits in the third tile for the next first half
         Tile::sync();
-        wt.take(0, cE);
-        wt.take(1, um1);
+        wt.take(0, um1);
         Tile::sync();
+
+        ChunkElim<P, kDivRounded> el;
+        double mx = 0.0, ss = 0.0;
+        assemble(std::false_type{}, el, ss, mx);
+        // back substitution with this lane's last unknown y and its left neighbour's (any segment)
+        const double y = W.y[lane_id];
+        const double yl = first_lane ? 0.0 : W.y[lane_slot(b, n, lane_r - 1)];
+        double x[P];
+        x[P - 1] = y;
+#pragma unroll
+        for (int i = P - 2; i >= 0; --i) x[i] = back_step(el.f[i], el.l[i], el.e[i], yl, x[i + 1]);
+        int bad = 0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) bad |= !(isfinite(x[i]) && x[i] >= 0.0);
+        bad = g.any(bad);
+        wt.put(0, x);
+        Tile::sync();
+        wt.flush(0, S_.u + woff);
+        if (t == 0) {
+            int bits = bad ? TG_ST_INVALID : 0;
+            if (s == 0) {
+                S_.iters[b] += 1;
+                if (turb) bits |= TG_ST_SEEDED;
+                if (flag == 2) bits |= TG_ST_CONVERGED;
+                if (W.sing[b]) bits |= TG_ST_SINGULAR;
+            }
+            if (bits) atomicOr(&S_.status[b], bits);
+        }
+        if (PHASE == 1) return;
+        // a converged profile stops here.  (A profile that this iteration left invalid in ANOTHER segment is not known to
+        // be so here: its memories advance once more, then the reduce kernel drops it.)
+        if (flag == 2 || bad) return;
+        Tile::sync();
+#pragma unroll
+        for (int i = 0; i < P; ++i) u[i + 1] = x[i];
+        // the neighbouring segment's new profile next to the boundary
+        if (edge_l || edge_r) {
+            const double *h = W.halo + kHaloQ * (b * (S - 1) + (edge_l ? s - 1 : s));
+            n_u0 = edge_l ? h[9] : h[10];
+            n_u1 = edge_l ? h[8] : h[11];
+        }
+    }
+
+    // ---- first half of an iteration ----
+    {
+        double ue[P];
+        if (PHASE == 0) {
+            double2 r0[4], r1[4], r2[4], r3[4], r4[4];
+            wt.fetch(S_.u + woff, r0);
+            wt.fetch(S_.uE + woff, r1);
+            wt.fetch(S_.DE + woff, r2);
+            wt.fetch(S_.cE + woff, r3);
+            wt.fetch(S_.um1 + woff, r4);
+            if (edge_l || edge_r) {
+                const int j1 = edge_l ? jh - 1 : jh + 1;
+                n_u0 = S_.u[off + jh];       // u changes in the second half only
+                n_u1 = S_.u[off + j1];
+                snapshot();
+            }
+            wt.stage(0, r0);
+            wt.stage(1, r1);
+            wt.stage(2, r2);
+            Tile::sync();
+            wt.take(0, u + 1);
+            wt.take(1, ue);
+            wt.take(2, DE);
+            Tile::sync();
+            wt.stage(0, r3);
+            wt.stage(1, r4);
+            Tile::sync();
+            wt.take(0, cE);
+            wt.take(1, um1);
+            Tile::sync();
+        } else {
+            wt.take(2, ue);
+            Tile::sync();
+        }
 
         auto split = [&](double pm, double p, double pp, bool first, bool last, double &D, double &c) {
             const double dpdx = ddx_edge1_point<EXACT>(pm, p, pp, first, last, rc);
@@ -227,77 +454,11 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
             h_c = n_c;
         }
         h_u = n_u0;
-    } else {
-        double2 r2[4], r3[4], r4[4];
-        wt.fetch(S_.DE + woff, r2);
-        wt.fetch(S_.cE + woff, r3);
-        wt.fetch(S_.um1 + woff, r4);
-        if (edge_l || edge_r) {
-            h_D = S_.DE[off + jh];
-            h_c = S_.cE[off + jh];
-        }
-        wt.stage(0, r2);
-        wt.stage(1, r3);
-        Tile::sync();
-        wt.take(0, DE);
-        wt.take(1, cE);
-        Tile::sync();
-        wt.stage(0, r4);
-        Tile::sync();
-        wt.take(0, um1);
-        Tile::sync();
-    }
 
-    // H2 = D, H3 = -c of the neighbouring lanes' nearest points; across a segment boundary the halo point's
-    // (every lane takes part in the shuffles; the edge lanes then substitute their halo values)
-    const double s2l = g.from_left(DE[P - 1], 1, 0.0), s3l = g.from_left(-cE[P - 1], 1, 0.0);
-    const double s2r = g.from_right(DE[0], 1, 0.0), s3r = g.from_right(-cE[0], 1, 0.0);
-    const double h2l = edge_l ? h_D : s2l;
-    const double h3l = edge_l ? -h_c : s3l;
-    const double h2r = edge_r ? h_D : s2r;
-    const double h3r = edge_r ? -h_c : s3r;
-    if (PHASE == 0) {
-        const double ul = g.from_left(u[P], 1, 0.0), ur = g.from_right(u[1], 1, 0.0);
-        u[0] = edge_l ? h_u : ul;
-        u[P + 1] = edge_r ? h_u : ur;
-    }
+        ChunkElim<P, kDivRounded> el;
+        double mx = 0.0, ss = 0.0;
+        assemble(std::true_type{}, el, ss, mx);
 
-    // assemble and eliminate (tango/HToMatrixFD.py:87-117 row by row, as in picard_1f_kernel)
-    ChunkElim<P, kDivRounded> el;
-    double hm2 = first_lane ? 0.0 : (h2l + DE[0]) / 2.0;
-    double hm3 = first_lane ? 0.0 : (h3l - cE[0]) / 2.0;
-    double bm = fbeta_point<kDivRounded>(hm2, hm3, rc.dx);
-    double mx = 0.0, ss = 0.0;
-    double h2c = DE[0], h3c = -cE[0];
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const int j = j0 + i;
-        const bool last = (i == P - 1) && last_lane;
-        const double h2n = (i == P - 1) ? h2r : DE[i < P - 1 ? i + 1 : 0];
-        const double h3n = (i == P - 1) ? h3r : -cE[i < P - 1 ? i + 1 : 0];
-        const double hp2 = (h2c + h2n) / 2.0;
-        const double hp3 = (h3c + h3n) / 2.0;
-        const double bp = fbeta_point<kDivRounded>(hp2, hp3, rc.dx);
-        const double H1 = Q.H1 ? Q.H1[j] : 1.0;
-        const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + j] : ((j < src_cut) ? S0 : 0.0);
-        double A, B, C, f;
-        fd_row<EXACT>(last, H1, um1[i], rc, UL, hm2, hm3, bm, hp2, hp3, bp, 0.0, 0.0, h7, A, B, C, f);
-        if (PHASE == 0) {
-            // residual of the current profile with the new matrix (tango/fieldgroups.py:139); zero-padded shifts
-            // at the two ends of the profile
-            const double r = A * u[i + 2] + B * u[i + 1] + C * u[i] - f;
-            ss += r * r;
-            mx = fmax(mx, fabs(f));
-        }
-        el.push(i, C, B, A, f);
-        hm2 = hp2;
-        hm3 = hp3;
-        bm = bp;
-        h2c = h2n;
-        h3c = h3n;
-    }
-
-    if (PHASE == 0) {
         // what the reduced system needs from this lane: its last row x_last + e x_next = f - l y_left with slack rho,
         // and its first unknown x_0 = F - L y_left - E y with slack tau (ChunkElim::finish forms the same values)
         double F = el.f[P - 2], L = el.l[P - 2], E = el.e[P - 2], tau = el.rho[P - 2];
@@ -309,45 +470,27 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
             E = -el.e[i] * E;
         }
         (void)L;
-        W.row[0][lane_id] = el.e[P - 1];
-        W.row[1][lane_id] = el.l[P - 1];
-        W.row[2][lane_id] = el.f[P - 1];
-        W.row[3][lane_id] = el.rho[P - 1];
-        W.row[4][lane_id] = F;
-        W.row[5][lane_id] = E;
-        W.row[6][lane_id] = tau;
+        // the lane's row of the reduced system, l y_{r-1} + (1 - e L0) y_r - e E0 y_{r+1} = f - e F0 with slack rho - e T0,
+        // from the first-row form (F0, E0, T0) of the lane to the right (ChunkElim::finish forms the same values); lane 63
+        // leaves its own last-row form and the reduce kernel combines it with what lane 0 of the next segment left
+        const double F0 = g.from_right(F, 1, 0.0), E0 = g.from_right(E, 1, 0.0), T0 = g.from_right(tau, 1, 1.0);
+        const double e7 = el.e[P - 1], l7 = el.l[P - 1], f7 = el.f[P - 1], r7 = el.rho[P - 1];
+        const bool own = (t == 63);
+        W.row[0][lane_id] = own ? e7 : l7;
+        W.row[1][lane_id] = own ? l7 : -(e7 * E0);
+        W.row[2][lane_id] = own ? f7 : f7 - e7 * F0;
+        W.row[3][lane_id] = own ? r7 : r7 - e7 * T0;
         mx = g.max(mx);
         ss = g.sum(ss);
         const int sing = g.any(el.singular);
         if (t == 0) {
+            double *Fq = W.first + 3 * (b * S + s);
+            Fq[0] = F;
+            Fq[1] = E;
+            Fq[2] = tau;
             W.ss[b * S + s] = ss;
             W.mx[b * S + s] = mx;
             if (sing) atomicOr(&W.sing[b], 1);
-        }
-    } else {
-        // back substitution with this lane's last unknown y and its left neighbour's (any segment)
-        const double y = W.y[lane_id];
-        const double yl = first_lane ? 0.0 : W.y[lane_slot(b, n, lane_r - 1)];
-        double x[P];
-        x[P - 1] = y;
-#pragma unroll
-        for (int i = P - 2; i >= 0; --i) x[i] = (el.f[i] - el.l[i] * yl) - el.e[i] * x[i + 1];
-        int bad = 0;
-#pragma unroll
-        for (int i = 0; i < P; ++i) bad |= !(isfinite(x[i]) && x[i] >= 0.0);
-        bad = g.any(bad);
-        wt.put(0, x);
-        Tile::sync();
-        wt.flush(0, S_.u + woff);
-        if (t == 0) {
-            int bits = bad ? TG_ST_INVALID : 0;
-            if (s == 0) {
-                S_.iters[b] += 1;
-                if (turb) bits |= TG_ST_SEEDED;
-                if (W.flag[b] == 2) bits |= TG_ST_CONVERGED;
-                if (W.sing[b]) bits |= TG_ST_SINGULAR;
-            }
-            if (bits) atomicOr(&S_.status[b], bits);
         }
     }
 }
@@ -357,7 +500,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
 // ------------------------------------------------------------------------------------------
 template <class G>
 __global__ void __launch_bounds__(G::T)
-picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
+picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next) {
     extern __shared__ double lds[];
     constexpr int P = 8;
     G g(lds);
@@ -377,26 +520,42 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
     for (int i = 0; i < P; ++i) {
         const int r = t * P + i;
         const int64_t k = lane_slot(b, n, r);
-        const double e = W.row[0][k], l = W.row[1][k], f = W.row[2][k], rho = W.row[3][k];
-        // first-row form of the lane to the right; an identity row past the end of the profile
-        const bool more = r + 1 < rows;
-        const int64_t k1 = lane_slot(b, n, more ? r + 1 : r);
-        const double F0 = more ? W.row[4][k1] : 0.0;
-        const double E0 = more ? W.row[5][k1] : 0.0;
-        const double T0 = more ? W.row[6][k1] : 1.0;
-        // l y_{r-1} + (1 - e L0) y_r - e E0 y_{r+1} = f - e F0 with slack rho - e T0, the diagonal formed from the
-        // slack (all terms of one sign for an M-matrix), as in ChunkElim::finish
-        const double sig = rho - e * T0;
-        const double s2 = l;
-        const double p2 = -(e * E0);
+        const double q0 = W.row[0][k], q1 = W.row[1][k], q2 = W.row[2][k], q3 = W.row[3][k];
+        double s2 = q0, p2 = q1, rhs = q2, sig = q3;
+        if ((r & 63) == 63) {
+            // the last lane of a segment left (e, l, f, rho); the first-row form of the lane to the right comes from the
+            // next segment, an identity row past the end of the profile
+            const bool more = r + 1 < rows;
+            const double *Fq = W.first + 3 * (b * S + (more ? (r + 1) >> 6 : 0));
+            const double F0 = more ? Fq[0] : 0.0;
+            const double E0 = more ? Fq[1] : 0.0;
+            const double T0 = more ? Fq[2] : 1.0;
+            sig = q3 - q0 * T0;
+            s2 = q1;
+            p2 = -(q0 * E0);
+            rhs = q2 - q0 * F0;
+        }
         const double d = sig - s2 - p2;
-        el.push_slack(i, s2, d, p2, f - e * F0, sig);
+        el.push_slack(i, s2, d, p2, rhs, sig);
     }
     double y[P];
     el.finish(g, y);
 #pragma unroll
     for (int i = 0; i < P; ++i) W.y[lane_slot(b, n, t * P + i)] = y[i];
     const int sing = g.any(el.singular);
+    if (next) {
+        // another iteration follows in this call: the boundary copies of the memories (as the first halves have just
+        // left them) and the new profile next to every boundary, for the kernel that does the second half of this
+        // iteration and the first half of the next
+        double *yl = lds + 8 * G::T;      // behind the group's exchange area: the lane unknowns in lane order
+#pragma unroll
+        for (int i = 0; i < P; ++i) yl[t * P + i] = y[i];
+        __syncthreads();
+        if (t < 2 * (S - 1)) {
+            if ((t & 1) == 0) boundary_snapshot(S_, W, b, t >> 1);
+            boundary_next_profile(S_, Q, W, b, t >> 1, t & 1, yl);
+        }
+    }
 
     // residual norm of the profile from the segments' partial sums (tango/fieldgroups.py:140, tango/solver.py:464-470)
     if (t == 0) {
@@ -424,7 +583,7 @@ size_t tg_seg_work_bytes(int64_t nb, int64_t n) {
 bool tg_seg_applies(const tg_state_1f *st, const tg_params_1f *q) {
     if (!q->work || tg_seg_work_bytes(st->nb, st->n) == 0 || q->work_bytes < tg_seg_work_bytes(st->nb, st->n)) return false;
     if (q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly ||
-        q->iters_per_launch > 1 || q->smooth_window > 1 || q->iterates || q->flux_mult)
+        q->smooth_window > 1 || q->iterates || q->flux_mult)
         return false;
     uintptr_t al = reinterpret_cast<uintptr_t>(st->u) | reinterpret_cast<uintptr_t>(st->um1) | reinterpret_cast<uintptr_t>(st->uE) |
                    reinterpret_cast<uintptr_t>(st->DE) | reinterpret_cast<uintptr_t>(st->cE) | reinterpret_cast<uintptr_t>(q->work);
@@ -441,16 +600,27 @@ int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
     const size_t tile = 4 * WaveTile<8>::kDoubles * sizeof(double);     // one tile for each of the four wavefronts
     const size_t lds0 = 3 * tile, lds1 = 2 * tile;
     const int64_t bounds = nb * (n / kSeg - 1);
-    hipLaunchKernelGGL(seg_halo_kernel, dim3((unsigned)((bounds + 255) / 256)), dim3(256), 0, s, *st, W);
-    hipLaunchKernelGGL((picard_seg_kernel<0>), dim3(grid), dim3(256), lds0, s, *st, *q, W);
     const int lanes = n / 64;      // threads of the reduce kernel: 8 reduced rows each
     const size_t lds_r = sizeof(double) * 8 * (size_t)lanes;
-    switch (lanes) {
-    case 128: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<128>>), dim3((unsigned)nb), dim3(128), lds_r, s, *st, *q, W); break;
-    case 256: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<256>>), dim3((unsigned)nb), dim3(256), lds_r, s, *st, *q, W); break;
-    case 512: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<512>>), dim3((unsigned)nb), dim3(512), lds_r, s, *st, *q, W); break;
-    default: return fail(TG_ERR_UNSUPPORTED, "segmented form: n must be 8192, 16384 or 32768%s");
+    if (lanes != 128 && lanes != 256 && lanes != 512) return fail(TG_ERR_UNSUPPORTED, "segmented form: n must be 8192, 16384 or 32768%s");
+    const size_t lds_n = lds_r + sizeof(double) * (size_t)(n / 8);       // + the lane unknowns of the profile
+    auto reduce = [&](int next) {
+        const size_t l = next ? lds_n : lds_r;
+        switch (lanes) {
+        case 128: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<128>>), dim3((unsigned)nb), dim3(128), l, s, *st, *q, W, next); break;
+        case 256: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<256>>), dim3((unsigned)nb), dim3(256), l, s, *st, *q, W, next); break;
+        default: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<512>>), dim3((unsigned)nb), dim3(512), l, s, *st, *q, W, next); break;
+        }
+    };
+    // iterations of one call: first half, reduce, then (second half + next first half), reduce, ... and the last second half
+    const int iters = q->iters_per_launch > 1 ? q->iters_per_launch : 1;
+    hipLaunchKernelGGL(seg_halo_kernel, dim3((unsigned)((bounds + 255) / 256)), dim3(256), 0, s, *st, W);
+    hipLaunchKernelGGL((picard_seg_kernel<0>), dim3(grid), dim3(256), lds0, s, *st, *q, W);
+    for (int k = 1; k < iters; ++k) {
+        reduce(1);
+        hipLaunchKernelGGL((picard_seg_kernel<2>), dim3(grid), dim3(256), lds0, s, *st, *q, W);
     }
+    reduce(0);
     hipLaunchKernelGGL((picard_seg_kernel<1>), dim3(grid), dim3(256), lds1, s, *st, *q, W);
     return launch_check();
 }
@@ -491,7 +661,7 @@ extern "C" int tg_picard_1f_step_static(const tg_state_1f *st, const tg_params_1
                                                    "whose step uses a work space); other sizes need none: call tg_picard_1f_step%s");
     if (need > (size_t)TG_STATIC_WORK_BYTES)
         return fail(TG_ERR_ARG, "tg_picard_1f_step_static: nb*n exceeds what the library's built-in work space of TG_STATIC_WORK_BYTES holds "
-                                "(about 4.4 million grid points in all, e.g. 512 profiles of 8192 points)%s");
+                                "(about 4.7 million grid points in all, e.g. 512 profiles of 8192 points)%s");
     if (st->nb == 0) return TG_OK;
     void *ws = nullptr;
     if (int e = scratch_on_current_device(&ws)) return e;
@@ -500,6 +670,6 @@ extern "C" int tg_picard_1f_step_static(const tg_state_1f *st, const tg_params_1
     p.work_bytes = TG_STATIC_WORK_BYTES;
     if (!tg_seg_applies(st, &p))
         return fail(TG_ERR_UNSUPPORTED, "tg_picard_1f_step_static: the segmented step needs the built-in flux, Cartesian geometry, one "
-                                        "iteration per call, no pseudo-timestep control, no iterate history and 16-byte aligned arrays%s");
+                                        "no pseudo-timestep control, no iterate history and 16-byte aligned arrays%s");
     return tg_seg_step(st, &p, S(stream));
 }

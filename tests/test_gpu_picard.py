@@ -737,6 +737,29 @@ def test_segmented_long_profiles_match_the_workgroup_kernel(tango, N, nb):
         assert np.allclose(A.err.to_host()[:, :k], B.err.to_host()[:, :k], rtol=1e-5, atol=1e-11)
 
 
+@pytest.mark.parametrize('N,nb', [(8192, 5), (16384, 2)])
+def test_segmented_multi_iteration_launch_equals_single_launches(tango, N, nb):
+    """k iterations of the segmented form in one call (the second half of an iteration and the first half of the next in
+    one kernel, the neighbouring segments' boundary values recomputed from their multipliers) against k calls of one
+    iteration: bit for bit the same profiles, EWMA memories, residual histories, stop iterations and status."""
+    from tango_amd.ensemble import OneFieldEnsemble, shestakov_ensemble
+    ens = shestakov_ensemble(nb, N)
+    for fixed, tol, total, a_prof in ((True, 1e-11, 12, 0.3), (False, 2e-3, 36, 0.3), (False, 2e-3, 36, 1.0)):
+        A = OneFieldEnsemble(ens, a_prof=a_prof, tol=tol, max_iter=total, fixed_count=fixed)
+        B = OneFieldEnsemble(ens, a_prof=a_prof, tol=tol, max_iter=total, fixed_count=fixed)
+        assert A.work is not None and B.work is not None
+        for _ in range(total):
+            A.step()
+        for k in ((5, 4, 3) if total == 12 else (2, 7, 3, 12, 12)):
+            B.step(iters=k)
+        ia, ib = A.iters.to_host(), B.iters.to_host()
+        assert np.array_equal(ia, ib) and np.array_equal(A.status.to_host(), B.status.to_host())
+        if not fixed:
+            assert np.all(ia < total) and np.all(A.status.to_host() & 1) and (len(set(ia.tolist())) > 1 or nb < 3)
+        for x, y in ((A.u, B.u), (A.uE, B.uE), (A.DE, B.DE), (A.cE, B.cE), (A.err, B.err)):
+            assert np.array_equal(y.to_host(), x.to_host())
+
+
 def test_flux_model_on_the_device():
     """A flux model that lives on the GPU (tests/device_flux_case.py).  In a process of its own: torch brings its own
     HIP runtime, which has to be loaded before libtango_hip.so for the two to share it, and this test session has
