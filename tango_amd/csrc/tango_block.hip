@@ -173,8 +173,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     constexpr bool COOP = FULL && (P == 4 || P == 8) && (G::kBlock || G::T == 64);
     using Tile = WaveTile<(P == 8) ? 8 : 4>;
     constexpr int KP = Tile::KP;
-    Tile wt(lds + (COOP ? (G::kBlock ? kExch3f * G::T : 0) + (threadIdx.x >> 6) * kTiles3f * Tile::kDoubles : 0));
-    const int64_t woff = off + (G::kBlock ? (int64_t)(threadIdx.x >> 6) * 64 * P : 0);   // this wavefront's segment
+    Tile wt(lds + (COOP ? (G::kBlock ? kExch3f * G::T : 0) + wave_in_block() * kTiles3f * Tile::kDoubles : 0));
+    const int64_t woff = off + (G::kBlock ? (int64_t)wave_in_block() * 64 * P : 0);   // this wavefront's segment
     const bool turb = !Q.frozen_turb;
 
     double u[3][P + 2], DE[3][P], cE[3][P];

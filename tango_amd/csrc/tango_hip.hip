@@ -56,10 +56,10 @@ tridiag_pf_kernel(const double *__restrict__ A, const double *__restrict__ B, co
     if (!exists) return;
     const int j0 = g.t() * P;
     const int64_t off = b * (int64_t)n;
-    const int64_t woff = G::kBlock ? off + (int64_t)(threadIdx.x >> 6) * 512 : off - (int64_t)((threadIdx.x & 63) / G::T) * n;
+    const int64_t woff = G::kBlock ? off + (int64_t)wave_in_block() * 512 : off - (int64_t)((threadIdx.x & 63) / G::T) * n;
     using Tile = WaveTile<8>;
     constexpr int NT = 2;      // two tiles per wavefront keep four wavefronts per SIMD resident
-    Tile wt(lds + (COOP_T ? (G::kBlock ? 8 * G::T : 0) + (threadIdx.x >> 6) * NT * Tile::kDoubles : 0));
+    Tile wt(lds + (COOP_T ? (G::kBlock ? 8 * G::T : 0) + wave_in_block() * NT * Tile::kDoubles : 0));
     double a[P], bb[P], c[P], d[P];
     if (COOP_T && coop) {
         double2 r0[4], r1[4], r2[4], r3[4];
@@ -397,7 +397,7 @@ residual_kernel(const double *__restrict__ A, const double *__restrict__ B, cons
                 const double *__restrict__ f, const double *__restrict__ u, const double *__restrict__ G,
                 const double *__restrict__ w, double *__restrict__ resid, double *__restrict__ sumsq, int64_t nb, int n) {
     const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block();
     if (b >= nb) return;
     const int64_t off = b * (int64_t)n;
     double mx = 0.0;
@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(256)
 ar1_noise_kernel(uint64_t seed, uint64_t sequence, double amplitude, double lambda, int damp, const double *__restrict__ taper,
                  double *__restrict__ out, int64_t nb, int n) {
     const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block();
     if (b >= nb) return;
     const Philox rng(seed);
     const double sd = sqrt(1.0 - lambda * lambda);
@@ -800,10 +800,10 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     double u[P + 2], ue[P], um1[P], DE[P], cE[P];
     double fl[GENERAL ? P : 1];
     // first element of this wavefront's 512 doubles: its first profile, or its segment of the workgroup's profile
-    const int64_t woff = G::kBlock ? off + (int64_t)(threadIdx.x >> 6) * 512 : off - (int64_t)((threadIdx.x & 63) / G::T) * S_.n;
+    const int64_t woff = G::kBlock ? off + (int64_t)wave_in_block() * 512 : off - (int64_t)((threadIdx.x & 63) / G::T) * S_.n;
     using Tile = WaveTile<8>;
     constexpr int NT = kCoopTiles<G>;
-    Tile wt(lds + (COOP_T ? (G::kBlock ? 8 * G::T : 0) + (threadIdx.x >> 6) * NT * Tile::kDoubles : 0));
+    Tile wt(lds + (COOP_T ? (G::kBlock ? 8 * G::T : 0) + wave_in_block() * NT * Tile::kDoubles : 0));
     // The old EWMA memory of the profile has weight 1 - a_prof: with a_prof = 1 (and whenever the turbulence step is
     // skipped) it is not read at all; zeros stand in, so that a_prof u + 0 * memory is u exactly.
     const bool need_ue = !Q.frozen_turb && (external || Q.a_prof != 1.0);
@@ -1026,7 +1026,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                     }
                     if (Q.smooth_window > 1) {
                         double *row = lds + Q.reserved_;
-                        if constexpr (!G::kBlock) row += (threadIdx.x >> 6) * 576 + ((threadIdx.x & 63) / G::T) * (G::T * 9);
+                        if constexpr (!G::kBlock) row += wave_in_block() * 576 + ((threadIdx.x & 63) / G::T) * (G::T * 9);
                         smooth_flux<P, G>(row, n, j0, (Q.smooth_window - 1) / 2, fl);
                     }
                     have_flux = true;

@@ -207,7 +207,8 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
     G g(lds);
     const int n = (int)S_.n;
     const int S = n / kSeg;
-    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // segment index over the ensemble
+    const int wave = wave_in_block();      // the same in every lane: say so
+    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;   // segment index over the ensemble
     if (w >= S_.nb * S) return;
     const int64_t b = w / S;
     const int s = (int)(w - b * S);
@@ -239,7 +240,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
 
     using Tile = WaveTile<8>;
     constexpr int NT = (PHASE == 1) ? 2 : 3;      // LDS tiles per wavefront: few enough for three wavefronts per SIMD
-    Tile wt(lds + (threadIdx.x >> 6) * NT * Tile::kDoubles);
+    Tile wt(lds + wave * NT * Tile::kDoubles);
 
     double u[P + 2], um1[P], DE[P], cE[P];
     // values at the point just outside this wavefront's segment, on the side of this lane if it is lane 0 or 63

@@ -75,6 +75,10 @@ __device__ __forceinline__ double swap_halves(double v, bool upper) {
     return __hiloint2double((int)(upper ? b[0] : b[1]), (int)(upper ? a[0] : a[1]));
 }
 
+// Index of this wavefront within its workgroup.  It is the same in every lane; read through the first lane so that the
+// compiler knows, and keeps what is derived from it (row offsets, tile addresses, per-profile parameters) in scalar registers.
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 template <int LPP>
 struct WaveGroup {
     static constexpr int T = LPP;
@@ -84,7 +88,12 @@ struct WaveGroup {
     __device__ int t() const { return t_; }
     // number of profiles handled by one workgroup of `threads` threads
     static constexpr int profiles_per_block(int threads) { return threads / LPP; }
-    __device__ int64_t profile_in_block() const { return threadIdx.x / LPP; }
+    // a whole wavefront per profile: the index is the same in every lane, and saying so keeps everything derived from it
+    // (status, per-profile parameters, row offsets) in scalar registers
+    __device__ int64_t profile_in_block() const {
+        if constexpr (LPP == 64) return wave_in_block();
+        else return threadIdx.x / LPP;
+    }
 
     // value held by lane t-h (fill when there is none)
     __device__ double from_left(double v, int h, double fill) const {
