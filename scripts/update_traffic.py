@@ -1,7 +1,7 @@
 """Turn the summaries written by scripts/profile_bench.sh (gpurun_out/prof_<tag>/summary.txt) into the numbers
 bench.py quotes beside its live timings (profiles/traffic.json) and copy the summaries to profiles/<round>_<tag>_summary.txt.
 
-    python scripts/update_traffic.py r02 metric_k64:metric_65536x512:64 metric_k1:metric_65536x512:1 c3:c3_16384x512:1 c4:c4_4096x8192:1
+    python scripts/update_traffic.py r02 metric_k64:metric_65536x512:64 metric_k1:metric_65536x512:1 c3:c3_16384x512:1 c4_k1:c4_4096x8192:1 c4_k16:c4_4096x8192:16
 
 Each argument is <profile tag>:<bench key prefix>:<iterations per launch of the timed kernel>.  HBM bytes per launch =
 (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the kernels of one step: on gfx950 FETCH_SIZE counts half the bytes of a
@@ -44,8 +44,16 @@ def main():
             multi = bool(re.search(r'picard_1f_kernel<.*, true>\(', name))
             if ('picard_1f_kernel' in name) and (multi != (k > 1)):
                 continue
+            # the segmented form's k iterations per call are a chain: k reduce kernels, k - 1 combined kernels, one of the rest
+            times = 1
+            if k > 1 and 'picard_seg_kernel<2>' in name:
+                times = k - 1
+            elif k > 1 and 'picard_seg_reduce_kernel' in name:
+                times = k
+            elif k == 1 and 'picard_seg_kernel<2>' in name:
+                continue
             if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
-                total += (2 * c['FETCH_SIZE'][1] + c['WRITE_SIZE'][1]) * 1024
+                total += times * (2 * c['FETCH_SIZE'][1] + c['WRITE_SIZE'][1]) * 1024
             if 'SQ_INSTS_VALU_FMA_F64' in c and ('picard_1f_kernel' in name):
                 f = 2 * c['SQ_INSTS_VALU_FMA_F64'][1] + c['SQ_INSTS_VALU_MUL_F64'][1] + c['SQ_INSTS_VALU_ADD_F64'][1] + c['SQ_INSTS_VALU_TRANS_F64'][1]
                 waves = c.get('SQ_WAVES', pmc[name].get('SQ_WAVES', (0, 0)))[1]
