@@ -847,8 +847,9 @@ class _FusedExternal1F(_Fused1F):
 
 
 class _FusedMapped1F(_FusedExternal1F):
-    """One field whose turbulence lives on a grid of its own (gridMapper = interfacegrids_gene.GridInterfaceTangoOutside: the
-    transport grid reaches beyond the turbulence grid at both ends).  Every step of tango/lodestro_method.py:327-388 stays
+    """One field whose turbulence lives on a grid of its own (gridMapper = interfacegrids_gene.GridInterfaceTangoOutside,
+    TangoOutsideExtrapCoeffs or TangoOutsideExtrapCoeffsBothSides: the transport grid reaches beyond the turbulence grid at
+    both ends; the latter two replace the coefficients beyond the trusted part of the turbulence grid by a fitted polynomial).  Every step of tango/lodestro_method.py:327-388 stays
     on the device: spline of the profile onto the turbulence grid (tg_spline_resample), its EWMA (tg_ewma_profiles), the
     flux model (built-in Shestakov flux, a model on the GPU, or a Python model on the host through page-locked buffers),
     smoothing (tg_moving_average), the split (tg_flux_split), the EWMA of D and c on the turbulence grid, the spline of
@@ -864,7 +865,8 @@ class _FusedMapped1F(_FusedExternal1F):
         f = s.fields[0]
         th = s.compute_all_H_all_fields.turbhandler
         m = f.lodestroMethod
-        if type(f.gridMapper) is not _ig.GridInterfaceTangoOutside or type(m) is not _lm.lm:
+        if type(f.gridMapper) not in (_ig.GridInterfaceTangoOutside, _ig.TangoOutsideExtrapCoeffs, _ig.TangoOutsideExtrapCoeffsBothSides) \
+                or type(m) is not _lm.lm:
             return None
         if m._fluxSplitter.ftheta != m._fluxSplitter._default_ftheta or f.coupledTo is not None:
             return None
@@ -890,10 +892,7 @@ class _FusedMapped1F(_FusedExternal1F):
         xG = np.ascontiguousarray(f.gridMapper.get_x_turbulence_grid(), dtype=np.float64)
         self.nt = nt = xG.size
         self.xT, self.xG = D.from_host(xT), D.from_host(xG)
-        # coefficients come back onto the transport points strictly inside the turbulence grid, zero elsewhere
-        # (tango/interfacegrids_gene.py:446-484)
-        self.lo = int(np.where(xT > xG[0])[0][0])
-        self.hi = int(np.where(xT < xG[-1])[0][-1]) + 1
+        self.lo, self.hi, self.zones = self._back_map(f.gridMapper, xT, xG)
         from .ensemble import device_arrays
         self.pT, self.uE_t, self.flux_t, self.D_t, self.c_t, self.DE_t, self.cE_t = device_arrays([((self.nb, nt), np.float64)] * 7, zero=True)
         wb = max(int(H.lib.tg_spline_work_bytes(self.nb, self.n)), int(H.lib.tg_spline_work_bytes(self.nb, nt)))
@@ -909,6 +908,44 @@ class _FusedMapped1F(_FusedExternal1F):
             self.DE_t.set(np.atleast_2d(m._EWMATurbD._yEWMA_lminus1))
             self.cE_t.set(np.atleast_2d(m._EWMATurbc._yEWMA_lminus1))
         self.seeded = m._EWMAProfile._yEWMA_lminus1 is not None
+
+    @staticmethod
+    def _back_map(mapper, xT, xG):
+        """How D and c come back onto the transport grid: the range [lo, hi) of transport points that take the spline
+        through the turbulence-grid values (zero elsewhere), and for the extrapolating mappers the stretches that take a
+        polynomial fitted to the points of a zone instead, each as (first zone point, zone points, matrix on the device,
+        first output point, output points).  The fit + evaluation of np.polyfit / np.polyval is linear in the data: its
+        matrix is built here once, by the same two NumPy routines applied to unit vectors."""
+        from . import interfacegrids_gene as _ig
+
+        def fit_matrix(z0, z1, out):
+            zone = np.flatnonzero((xG >= z0) & (xG <= z1))
+            if zone.size == 0 or out.size == 0:
+                return None
+            coef = np.polyfit(xG[zone], np.eye(zone.size), mapper.polynomialDegree)        # (degree + 1, zone points)
+            M = np.stack([np.polyval(coef[:, z], xT[out]) for z in range(zone.size)], axis=1)
+            return (int(zone[0]), int(zone.size), H.DeviceArray.from_host(np.ascontiguousarray(M)), int(out[0]), int(out.size))
+
+        if type(mapper) is _ig.GridInterfaceTangoOutside:
+            # the transport points strictly inside the turbulence grid (tango/interfacegrids_gene.py:446-484)
+            return int(np.where(xT > xG[0])[0][0]), int(np.where(xT < xG[-1])[0][-1]) + 1, []
+        if type(mapper) is _ig.TangoOutsideExtrapCoeffs:
+            right_edge = mapper.xExtrapZoneRight
+            fits = [(mapper.xExtrapZoneLeft, mapper.xExtrapZoneRight, np.flatnonzero(xT > right_edge))]
+        else:       # both sides: the inner fit is applied after the spline and replaces it where the two overlap (:349-360)
+            right_edge = mapper.xOuterExtrapZoneRight
+            fits = [(mapper.xInnerExtrapZoneLeft, mapper.xInnerExtrapZoneRight, np.flatnonzero(xT < mapper.xInnerExtrapZoneLeft)),
+                    (mapper.xOuterExtrapZoneLeft, mapper.xOuterExtrapZoneRight, np.flatnonzero(xT > right_edge))]
+        inside = np.flatnonzero((xT >= xG[0]) & (xT <= right_edge))
+        lo, hi = (int(inside[0]), int(inside[-1]) + 1) if inside.size else (0, 0)
+        zones = [z for z in (fit_matrix(*fit) for fit in fits) if z is not None]
+        return lo, hi, zones
+
+    def _onto_transport_grid(self, src, nonneg, out):
+        """D or c from the turbulence grid onto the transport grid (tango/lodestro_method.py:372)."""
+        self._resample(self.xG, src, self.nt, self.xT, self.n, self.lo, self.hi, nonneg, out)
+        for z_lo, z_n, M, o_lo, rows in self.zones:
+            H.check(H.lib.tg_zone_apply(src.ptr, self.nb, self.nt, z_lo, z_n, M.ptr, out.ptr, self.n, o_lo, rows, int(nonneg), H.stream()))
 
     def params(self, s):
         q = _FusedExternal1F.params(self, s)
@@ -986,8 +1023,8 @@ class _FusedMapped1F(_FusedExternal1F):
                 H.check(H.lib.tg_ewma_profiles(self.D_t.ptr, self.DE_t.ptr, float(a_turb), self.status.ptr, self.nb, self.nt, H.stream()))
                 H.check(H.lib.tg_ewma_profiles(self.c_t.ptr, self.cE_t.ptr, float(a_turb), self.status.ptr, self.nb, self.nt, H.stream()))
                 # back onto the transport grid (:372), D kept non-negative (tango/interfacegrids_gene.py:59-64)
-                self._resample(self.xG, self.DE_t, self.nt, self.xT, self.n, self.lo, self.hi, True, self.DE)
-                self._resample(self.xG, self.cE_t, self.nt, self.xT, self.n, self.lo, self.hi, False, self.cE)
+                self._onto_transport_grid(self.DE_t, True, self.DE)
+                self._onto_transport_grid(self.cE_t, False, self.cE)
                 if not self.seeded:
                     H.check(H.lib.tg_status_or(self.status.ptr, self.nb, H.ST_SEEDED, H.stream()))
                     self.seeded = True

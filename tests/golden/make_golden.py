@@ -470,6 +470,33 @@ def g17():
 
 
 # ---------------------------------------------------------------- G9 three-field trajectories
+def g19():
+    """One-field runs whose coefficients are extrapolated beyond the trusted part of the turbulence grid
+    (tango/interfacegrids_gene.py:90-178 at the outer boundary, :181-245 at both): transport grid 0..1 (N=120),
+    turbulence grid 0.1..0.9 (N=300), Shestakov flux on the turbulence grid, as in g16."""
+    from tango import interfacegrids_gene as ig
+    N, NG = 120, 300
+    x = np.linspace(0, 1, N)
+    xg = np.linspace(0.1, 0.9, NG); dxg = xg[1] - xg[0]
+    th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
+    out = dict(run_N=N, run_NG=NG)
+    for tag, mapper in (('outer', ig.TangoOutsideExtrapCoeffs(x, xg, 0.6, 0.8, 1)),
+                        ('both', ig.TangoOutsideExtrapCoeffsBothSides(x, xg, 0.2, 0.35, 0.6, 0.8, 2))):
+        lm = lodestro_method.lm(0.3, 1.0, th)
+        f0 = multifield.Field(label='n', rightBC=0.05, profile_mminus1=1 - 0.5 * x, compute_all_H=ComputeAllH1F(1.0, 0.3),
+                              gridMapper=mapper, lodestroMethod=lm)
+        multifield.check_fields_initialize([f0])
+        call = multifield.ComputeAllHAllFields([f0], lodestro_method.TurbulenceHandler(dxg, x, shest.AnalyticFluxModel(dxg)))
+        s = tsolver.Solver(1, x, np.array([0, 0.5]), 25, 1e-14, call, [f0])
+        s.take_timestep()
+        out[tag + '_err'] = s.errHistoryFinal.copy()
+        out[tag + '_final'] = s.profiles['n'].copy()
+        out[tag + '_it2'] = s.profilesAllIterations['n'][2].copy()
+        out[tag + '_DE'] = lm._EWMATurbD._yEWMA_lminus1.copy()
+        print(tag, 'iterations', len(s.errHistoryFinal), 'last err', s.errHistoryFinal[-1])
+    save('g19_gridmap_extrap_runs', **out)
+
+
 def run_ref_3f(N, nu0, BCs, a_turb, a_prof, tol, maxit, inner=0, dt=1e6, keep=(), ic=None, **solver_kw):
     dx = 1 / (N - 1); x = np.arange(N) * dx
     th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
@@ -581,6 +608,6 @@ def g11():
 
 
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18']
+    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18', 'g19']
     for w in which:
         globals()[w]()

@@ -259,6 +259,67 @@ def test_solver_with_grid_mapper(tango, golden, path):
     assert relerr(lm._EWMATurbD._yEWMA_lminus1, g['run_DE']) < 1e-10
 
 
+def test_extrapolated_coefficients_on_the_device(tango, golden):
+    """The back-map of the extrapolating mappers as the device pipeline does it (spline over the trusted range, the
+    least-squares polynomial beyond it as a fixed matrix applied by tg_zone_apply) against the reference's own maps of
+    sample coefficients (golden g16: outer boundary only, g17: both boundaries)."""
+    from tango_amd import _hip as H
+    from tango_amd.solver import _FusedMapped1F
+    g16, g17 = golden('g16_gridmap'), golden('g17_gridmap_more')
+    xT, xG = g17['xT'], g17['xG']
+    ig = tango.interfacegrids_gene
+    D = H.DeviceArray
+    xT_d, xG_d = D.from_host(xT), D.from_host(xG)
+    work = D((int(H.lib.tg_spline_work_bytes(2, xG.size)) // 8,))
+    cases = ((ig.TangoOutsideExtrapCoeffs(xT, xG, 0.55, 0.7, 2), g16['ext_D_on_T'], g16['ext_c_on_T']),
+             (ig.TangoOutsideExtrapCoeffsBothSides(xT, xG, 0.2, 0.32, 0.55, 0.7, 2), g17['both_D_on_T'], g17['both_c_on_T']))
+    for mapper, D_ref, c_ref in cases:
+        lo, hi, zones = _FusedMapped1F._back_map(mapper, xT, xG)
+        assert len(zones) == (2 if 'BothSides' in type(mapper).__name__ else 1)
+        for src, nonneg, ref in ((g17['Dg'], True, D_ref), (g17['cg'], False, c_ref)):
+            src_d = D.from_host(np.stack([src, 0.5 * src]))             # two profiles: the second checks the row strides
+            out = D((2, xT.size), zero=True)
+            H.check(H.lib.tg_spline_resample(xG_d.ptr, src_d.ptr, 2, xG.size, xT_d.ptr, xT.size, lo, hi, int(nonneg), out.ptr, work.ptr,
+                                             work.nbytes, H.stream()))
+            for z_lo, z_n, M, o_lo, rows in zones:
+                H.check(H.lib.tg_zone_apply(src_d.ptr, 2, xG.size, z_lo, z_n, M.ptr, out.ptr, xT.size, o_lo, rows, int(nonneg), H.stream()))
+            got = out.to_host()
+            assert relerr(got[0], ref) < 1e-12 and relerr(got[1], 0.5 * ref) < 1e-12
+            if nonneg:
+                assert got.min() >= 0.0 and np.any(ref == 0.0)
+
+
+@pytest.mark.parametrize('tag', ['outer', 'both'])
+@pytest.mark.parametrize('path', ['pipeline', 'generic'])
+def test_solver_with_extrapolating_grid_mapper(tango, golden, tag, path):
+    """The mappers that extrapolate the coefficients beyond the trusted part of the turbulence grid (the one the reference's
+    GENE drivers use, and its two-sided variant), against the reference's trajectories: device-resident pipeline (the fit
+    as a fixed matrix, tg_zone_apply) and generic path (NumPy fit on the host)."""
+    g = golden('g19_gridmap_extrap_runs')
+    N, NG = int(g['run_N']), int(g['run_NG'])
+    x = np.linspace(0, 1, N)
+    xg = np.linspace(0.1, 0.9, NG); dxg = xg[1] - xg[0]
+    sh = tango.extras.shestakov_nonlinear_diffusion
+    ig = tango.interfacegrids_gene
+    mapper = ig.TangoOutsideExtrapCoeffs(x, xg, 0.6, 0.8, 1) if tag == 'outer' else ig.TangoOutsideExtrapCoeffsBothSides(x, xg, 0.2, 0.35, 0.6, 0.8, 2)
+    lm = tango.lodestro_method.lm(0.3, 1.0, {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10})
+    cb = sh.ComputeAllH(1.0, 0.3)
+    if path == 'generic':
+        cb = (lambda inner: (lambda t, xx, p, HT: inner(t, xx, p, HT)))(cb)
+    f = tango.multifield.Field(label='n', rightBC=0.05, profile_mminus1=1 - 0.5 * x, compute_all_H=cb, gridMapper=mapper, lodestroMethod=lm)
+    tango.multifield.check_fields_initialize([f])
+    call = tango.multifield.ComputeAllHAllFields([f], tango.lodestro_method.TurbulenceHandler(dxg, x, sh.AnalyticFluxModel(dxg)))
+    s = tango.solver.Solver(1, x, np.array([0, 0.5]), 25, 1e-14, call, [f], detectStaticH=False, iterationsPerCheck=5)
+    assert (type(s._fused).__name__ == '_FusedMapped1F') == (path == 'pipeline')
+    s.take_timestep()
+    assert len(s.errHistoryFinal) == len(g[tag + '_err'])
+    assert relerr(s.profilesAllIterations['n'][2], g[tag + '_it2']) < 1e-10
+    assert relerr(s.profiles['n'], g[tag + '_final']) < 1e-10
+    assert relerr(lm._EWMATurbD._yEWMA_lminus1, g[tag + '_DE']) < 1e-10
+    # measured: profiles 1.5e-11, D 1.2e-11; the late residuals (5e-5 and below, differences of O(1) terms) then agree to 1e-6
+    assert np.allclose(s.errHistoryFinal, g[tag + '_err'], rtol=2e-5, atol=1e-12)
+
+
 def test_grid_mapper_pipeline_ensemble(tango):
     """The device-resident mapped pipeline on an ensemble whose members stop on their own iterations, member by member against
     the same run on the generic path (same kernels for every map, host arrays in between)."""
