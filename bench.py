@@ -198,7 +198,7 @@ def main():
     per_gpu = args.profiles_per_gpu or per_gpu
     n = args.n or n
     kper = max(1, args.iters_per_launch or kdef)
-    if fields == 3 or 512 < n < 8192:
+    if fields == 3 or 512 < n < 4096:
         kper = 1                                   # these kernels run one iteration per launch
     check = max(kper, args.check_every - args.check_every % kper)
     k1_steps = max(8, args.steps // 4) if kper > 1 else 0
@@ -287,7 +287,7 @@ def main():
         bytes_per_iter = shard * n * bpp
         tag = f'{args.config}_{per_gpu}x{n}'
         hbm_k1 = None
-        segmented = fields == 1 and n >= 8192
+        segmented = fields == 1 and n >= 4096
         if kper == 1 or segmented:
             # every iteration crosses HBM (the segmented form's k iterations per call are a chain of kernels)
             per_launch = args.steps / launches

@@ -241,7 +241,7 @@ typedef struct {
     int32_t reserved_;     /* set to 0; used by the library */
     double tread_max_change;
     double tread_initial_dtau;
-    /* Optional work space of tg_picard_1f_work_bytes(nb, n) bytes.  With it, profiles of n = 8192, 16384 or 32768
+    /* Optional work space of tg_picard_1f_work_bytes(nb, n) bytes.  With it, profiles of n = 4096, 8192, 16384 or 32768
      * points (built-in flux, Cartesian, no pseudo-timestep control) are stepped in segments of 512 points, one
      * wavefront each, in three kernels: turbulence update + assembly + elimination per segment; the reduced system
      * of the segment-lane unknowns per profile; back substitution per segment (with iters_per_launch > 1 the back
@@ -273,7 +273,7 @@ int tg_picard_1f_step(const tg_state_1f *state, const tg_params_1f *params, tg_s
 
 /* The same step for callers that cannot allocate device memory (code under HIP graph capture, serving loops,
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  It is tg_picard_1f_step for the profile
- * lengths whose step needs a work space (n = 8192, 16384, 32768; built-in flux, Cartesian),
+ * lengths whose step can use a work space (n = 4096, 8192, 16384, 32768; built-in flux, Cartesian),
  * with params->work ignored: the work space is a TG_STATIC_WORK_BYTES array inside the library, one per GPU, held
  * until the process ends.  tg_picard_1f_work_bytes(nb, n) must not exceed TG_STATIC_WORK_BYTES (about 4.7 million
  * grid points in all, e.g. 512 x 8192); larger ensembles get TG_ERR_ARG, other profile lengths TG_ERR_UNSUPPORTED

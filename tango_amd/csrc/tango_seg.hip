@@ -1,4 +1,4 @@
-// Segmented form of the fused one-field Picard iteration for long profiles (n = S x 512, S > 8).
+// Segmented form of the fused one-field Picard iteration for long profiles (n = S x 512, S = 8, 16, 32, 64).
 //
 // A workgroup per profile runs out of registers beyond 4096 points (one resident workgroup per CU, its load,
 // compute and store phases serialised).  Here every 512-point segment is one wavefront, exactly as a whole profile
@@ -577,7 +577,7 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next) {
 
 // entry points for tango_hip.hip (C++ linkage: not part of the C ABI)
 size_t tg_seg_work_bytes(int64_t nb, int64_t n) {
-    if (n != 8192 && n != 16384 && n != 32768) return 0;      // n/64 threads solve the reduced system: a power of two
+    if (n != 4096 && n != 8192 && n != 16384 && n != 32768) return 0;      // n/64 threads solve the reduced system: a power of two
     return seg_work_bytes(nb, n);
 }
 
@@ -603,11 +603,12 @@ int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
     const int64_t bounds = nb * (n / kSeg - 1);
     const int lanes = n / 64;      // threads of the reduce kernel: 8 reduced rows each
     const size_t lds_r = sizeof(double) * 8 * (size_t)lanes;
-    if (lanes != 128 && lanes != 256 && lanes != 512) return fail(TG_ERR_UNSUPPORTED, "segmented form: n must be 8192, 16384 or 32768%s");
+    if (lanes != 64 && lanes != 128 && lanes != 256 && lanes != 512) return fail(TG_ERR_UNSUPPORTED, "segmented form: n must be 4096, 8192, 16384 or 32768%s");
     const size_t lds_n = lds_r + sizeof(double) * (size_t)(n / 8);       // + the lane unknowns of the profile
     auto reduce = [&](int next) {
         const size_t l = next ? lds_n : lds_r;
         switch (lanes) {
+        case 64: hipLaunchKernelGGL((picard_seg_reduce_kernel<WaveGroup<64>>), dim3((unsigned)nb), dim3(64), l, s, *st, *q, W, next); break;
         case 128: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<128>>), dim3((unsigned)nb), dim3(128), l, s, *st, *q, W, next); break;
         case 256: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<256>>), dim3((unsigned)nb), dim3(256), l, s, *st, *q, W, next); break;
         default: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<512>>), dim3((unsigned)nb), dim3(512), l, s, *st, *q, W, next); break;
@@ -658,7 +659,7 @@ int scratch_on_current_device(void **out) {
 extern "C" int tg_picard_1f_step_static(const tg_state_1f *st, const tg_params_1f *q, tg_stream stream) {
     if (int e = tg_picard_1f_validate(st, q)) return e;
     const size_t need = tg_seg_work_bytes(st->nb, st->n);
-    if (need == 0) return fail(TG_ERR_UNSUPPORTED, "tg_picard_1f_step_static steps profiles of 8192, 16384 or 32768 points (the sizes "
+    if (need == 0) return fail(TG_ERR_UNSUPPORTED, "tg_picard_1f_step_static steps profiles of 4096, 8192, 16384 or 32768 points (the sizes "
                                                    "whose step uses a work space); other sizes need none: call tg_picard_1f_step%s");
     if (need > (size_t)TG_STATIC_WORK_BYTES)
         return fail(TG_ERR_ARG, "tg_picard_1f_step_static: nb*n exceeds what the library's built-in work space of TG_STATIC_WORK_BYTES holds "

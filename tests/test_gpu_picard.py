@@ -254,21 +254,22 @@ def test_fused_step_other_sizes_vs_oracle(tango, N):
     for _ in range(its):
         E.step()
     H7 = orc.shestakov_source(ens['x'], ens['S0'], ens['delta'])
-    # measured after 50 iterations of the example problem (profiles/r02_parity_report.json): 2e-11 at N = 2048, 1.2e-10 at 4096
+    # measured after 50 iterations of the example problem (profiles/r02_parity_report.json): D and c 2e-11 at N = 2048,
+    # 1.0e-10 and 1.5e-10 at 4096 (profiles 1.4e-11)
     bar = TOL if N <= 2048 else 3e-10
     for b in range(nb):
         st = orc.State1F(ens['u0'][b])
         for _ in range(its):
             orc.picard_step_1f(st, 1e4, ens['dx'], ens['nL'][b], np.ones(N), H7[b], 0.3, 0.3)
-        assert relerr(E.u.to_host()[b], st.u) < bar
+        assert relerr(E.u.to_host()[b], st.u) < TOL
         assert relerr(E.DE.to_host()[b], st.DE) < bar and relerr(E.cE.to_host()[b], st.cE) < bar
 
 
 def test_fine_grid_vs_reference(tango, golden):
     """N = 8192 (cond ~1e11), 50 iterations of the reference's trajectory.  Measured (profiles/r02_parity_report.json):
-    the profile agrees with the reference to 7e-11 (1.3e-10 element-wise), D and c to 1.5e-10 and 2.2e-10: D ~ (u'/u)^2
+    the profile agrees with the reference to 1.6e-11 (3.1e-11 element-wise), D and c to 1.0e-10 and 1.5e-10: D ~ (u'/u)^2
     amplifies point-to-point rounding noise of u by 2 / (dx u'/u) ~ 3e4 on this grid, so 1e-10 in D would need the two
-    solves to agree to 3e-15.  Bars: 3e-10 for the profile."""
+    solves to agree to 3e-15.  Bars: 1e-10 for the final profile, 1.5e-10 element by element, 2e-10 for early iterates."""
     from tango_amd.ensemble import OneFieldEnsemble
     g = golden('g8_onefield')
     N = 8192; x = np.arange(N) * (1 / (N - 1))
@@ -277,8 +278,8 @@ def test_fine_grid_vs_reference(tango, golden):
     for it in range(50):
         E.step()
         if it in (0, 10):
-            assert relerr(E.u.to_host()[0], g[f'N8192_it{it}_u']) < 3e-10
-    assert relerr(E.u.to_host()[0], g['N8192_final']) < 3e-10 and relerr_elem(E.u.to_host()[0], g['N8192_final']) < 5e-10
+            assert relerr(E.u.to_host()[0], g[f'N8192_it{it}_u']) < 2e-10       # measured 1.05e-10 on an early iterate
+    assert relerr(E.u.to_host()[0], g['N8192_final']) < TOL and relerr_elem(E.u.to_host()[0], g['N8192_final']) < 1.5e-10
     assert np.allclose(E.err.to_host()[0], g['N8192_err'], rtol=1e-4)
 
 
@@ -713,9 +714,9 @@ def test_flux_smoothing_inside_the_fused_step(tango, N, nb, window, k):
         E.step()
 
 
-@pytest.mark.parametrize('N,nb', [(8192, 3), (16384, 2)])
+@pytest.mark.parametrize('N,nb', [(4096, 3), (8192, 3), (16384, 2)])
 def test_segmented_long_profiles_match_the_workgroup_kernel(tango, N, nb):
-    """Profiles of 8192 points and more are stepped in 512-point segments (three kernels, a work space); the result
+    """Profiles of 4096 points and more are stepped in 512-point segments (three kernels, a work space); the result
     must be the one-workgroup-per-profile kernel's: profiles, EWMA memories, residual history, stop iterations."""
     from tango_amd.ensemble import OneFieldEnsemble, shestakov_ensemble
     ens = shestakov_ensemble(nb, N)
@@ -737,7 +738,7 @@ def test_segmented_long_profiles_match_the_workgroup_kernel(tango, N, nb):
         assert np.allclose(A.err.to_host()[:, :k], B.err.to_host()[:, :k], rtol=1e-5, atol=1e-11)
 
 
-@pytest.mark.parametrize('N,nb', [(8192, 5), (16384, 2)])
+@pytest.mark.parametrize('N,nb', [(4096, 4), (8192, 5), (16384, 2)])
 def test_segmented_multi_iteration_launch_equals_single_launches(tango, N, nb):
     """k iterations of the segmented form in one call (the second half of an iteration and the first half of the next in
     one kernel, the neighbouring segments' boundary values recomputed from their multipliers) against k calls of one

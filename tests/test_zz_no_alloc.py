@@ -27,7 +27,7 @@ def _run(nb, n, its, static):
 def test_static_work_space_matches_caller_work_space():
     import tango_amd
     assert tango_amd.device_count() > 0
-    for nb, n, its in ((24, 8192, 3), (5, 8192, 2), (3, 16384, 2)):
+    for nb, n, its in ((24, 8192, 3), (5, 8192, 2), (3, 16384, 2), (7, 4096, 2)):
         got = _run(nb, n, its, static=True)
         ref = _run(nb, n, its, static=False)
         for k in ref:
