@@ -1,7 +1,7 @@
 """Turn the summaries written by scripts/profile_bench.sh (gpurun_out/prof_<tag>/summary.txt) into the numbers
 bench.py quotes beside its live timings (profiles/traffic.json) and copy the summaries to profiles/<round>_<tag>_summary.txt.
 
-    python scripts/update_traffic.py r02 metric_k64:metric_65536x512:64 metric_k1:metric_65536x512:1 c3:c3_16384x512:1 c4_k1:c4_4096x8192:1 c4_k16:c4_4096x8192:16
+    python scripts/update_traffic.py r02 metric_k64:metric_65536x512:64 metric_k1:metric_65536x512:1 c2_k64:c2_65536x256:64 c3:c3_16384x512:1 c4_k1:c4_4096x8192:1 c4_k16:c4_4096x8192:16
 
 Each argument is <profile tag>:<bench key prefix>:<iterations per launch of the timed kernel>.  HBM bytes per launch =
 (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the kernels of one step: on gfx950 FETCH_SIZE counts half the bytes of a
