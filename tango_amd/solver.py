@@ -849,7 +849,9 @@ class _FusedExternal1F(_Fused1F):
 class _FusedMapped1F(_FusedExternal1F):
     """One field whose turbulence lives on a grid of its own (gridMapper = interfacegrids_gene.GridInterfaceTangoOutside,
     TangoOutsideExtrapCoeffs or TangoOutsideExtrapCoeffsBothSides: the transport grid reaches beyond the turbulence grid at
-    both ends; the latter two replace the coefficients beyond the trusted part of the turbulence grid by a fitted polynomial).  Every step of tango/lodestro_method.py:327-388 stays
+    both ends; the latter two replace the coefficients beyond the trusted part of the turbulence grid by a fitted polynomial;
+    or GridInterfaceTangoInside: the turbulence grid reaches beyond the outer end of the transport grid and the profile is
+    continued there by a fitted straight line).  Every step of tango/lodestro_method.py:327-388 stays
     on the device: spline of the profile onto the turbulence grid (tg_spline_resample), its EWMA (tg_ewma_profiles), the
     flux model (built-in Shestakov flux, a model on the GPU, or a Python model on the host through page-locked buffers),
     smoothing (tg_moving_average), the split (tg_flux_split), the EWMA of D and c on the turbulence grid, the spline of
@@ -865,8 +867,8 @@ class _FusedMapped1F(_FusedExternal1F):
         f = s.fields[0]
         th = s.compute_all_H_all_fields.turbhandler
         m = f.lodestroMethod
-        if type(f.gridMapper) not in (_ig.GridInterfaceTangoOutside, _ig.TangoOutsideExtrapCoeffs, _ig.TangoOutsideExtrapCoeffsBothSides) \
-                or type(m) is not _lm.lm:
+        if type(f.gridMapper) not in (_ig.GridInterfaceTangoOutside, _ig.TangoOutsideExtrapCoeffs, _ig.TangoOutsideExtrapCoeffsBothSides,
+                                      _ig.GridInterfaceTangoInside) or type(m) is not _lm.lm:
             return None
         if m._fluxSplitter.ftheta != m._fluxSplitter._default_ftheta or f.coupledTo is not None:
             return None
@@ -893,6 +895,7 @@ class _FusedMapped1F(_FusedExternal1F):
         self.nt = nt = xG.size
         self.xT, self.xG = D.from_host(xT), D.from_host(xG)
         self.lo, self.hi, self.zones = self._back_map(f.gridMapper, xT, xG)
+        self.fwd_lo, self.fwd_hi, self.fwd_nonneg, self.fwd_zones = self._forward_map(f.gridMapper, xT, xG)
         from .ensemble import device_arrays
         self.pT, self.uE_t, self.flux_t, self.D_t, self.c_t, self.DE_t, self.cE_t = device_arrays([((self.nb, nt), np.float64)] * 7, zero=True)
         wb = max(int(H.lib.tg_spline_work_bytes(self.nb, self.n)), int(H.lib.tg_spline_work_bytes(self.nb, nt)))
@@ -908,6 +911,30 @@ class _FusedMapped1F(_FusedExternal1F):
             self.DE_t.set(np.atleast_2d(m._EWMATurbD._yEWMA_lminus1))
             self.cE_t.set(np.atleast_2d(m._EWMATurbc._yEWMA_lminus1))
         self.seeded = m._EWMAProfile._yEWMA_lminus1 is not None
+
+    @staticmethod
+    def _forward_map(mapper, xT, xG):
+        """How the profile goes onto the turbulence grid: the range [lo, hi) of turbulence points that take the spline
+        through the transport-grid values, whether negative values are cut off, and for a turbulence grid that reaches
+        beyond the transport grid the stretches that continue the profile by the straight line through its last point with
+        the least-squares slope of its last ten points (tango/interfacegrids_gene.py:545-604): that line is linear in the
+        data, value(x) = y_last + (x - x_last) sum_z d_z (y_z - y_last) / sum_z d_z^2 with d_z = x_z - x_last, so it is
+        applied as a fixed matrix over those ten points."""
+        from . import interfacegrids_gene as _ig
+        if type(mapper) is not _ig.GridInterfaceTangoInside:
+            return 0, xG.size, False, []
+        inside = np.flatnonzero((xG > xT[0]) & (xG < xT[-1]))
+        lo, hi = (int(inside[0]), int(inside[-1]) + 1) if inside.size else (0, 0)
+        pts = min(10, xT.size)
+        d = xT[-pts:] - xT[-1]
+        w = d / np.dot(d, d)
+        zones = []
+        for out in (np.arange(0, lo), np.arange(hi, xG.size)):
+            if out.size:
+                M = (xG[out] - xT[-1])[:, None] * w[None, :]
+                M[:, -1] += 1.0 - (xG[out] - xT[-1]) * w.sum()
+                zones.append((xT.size - pts, pts, H.DeviceArray.from_host(np.ascontiguousarray(M)), int(out[0]), int(out.size)))
+        return lo, hi, True, zones
 
     @staticmethod
     def _back_map(mapper, xT, xG):
@@ -929,6 +956,9 @@ class _FusedMapped1F(_FusedExternal1F):
         if type(mapper) is _ig.GridInterfaceTangoOutside:
             # the transport points strictly inside the turbulence grid (tango/interfacegrids_gene.py:446-484)
             return int(np.where(xT > xG[0])[0][0]), int(np.where(xT < xG[-1])[0][-1]) + 1, []
+        if type(mapper) is _ig.GridInterfaceTangoInside:
+            # the transport points to the right of the first turbulence point (:486-526)
+            return int(np.where(xT > xG[0])[0][0]), xT.size, []
         if type(mapper) is _ig.TangoOutsideExtrapCoeffs:
             right_edge = mapper.xExtrapZoneRight
             fits = [(mapper.xExtrapZoneLeft, mapper.xExtrapZoneRight, np.flatnonzero(xT > right_edge))]
@@ -995,7 +1025,10 @@ class _FusedMapped1F(_FusedExternal1F):
                         break
                     self._verify_static(s)
                 # profile onto the turbulence grid and its EWMA there (tango/lodestro_method.py:344-345)
-                self._resample(self.xT, self.u, self.n, self.xG, self.nt, 0, self.nt, False, self.pT)
+                self._resample(self.xT, self.u, self.n, self.xG, self.nt, self.fwd_lo, self.fwd_hi, self.fwd_nonneg, self.pT)
+                for z_lo, z_n, M, o_lo, rows in self.fwd_zones:
+                    H.check(H.lib.tg_zone_apply(self.u.ptr, self.nb, self.n, z_lo, z_n, M.ptr, self.pT.ptr, self.nt, o_lo, rows,
+                                                int(self.fwd_nonneg), H.stream()))
                 H.check(H.lib.tg_ewma_profiles(self.pT.ptr, self.uE_t.ptr, float(a_prof), self.status.ptr, self.nb, self.nt, H.stream()))
                 # flux on the turbulence grid (:350), smoothing (:359-362)
                 if builtin:

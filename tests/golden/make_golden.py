@@ -497,6 +497,30 @@ def g19():
     save('g19_gridmap_extrap_runs', **out)
 
 
+def g20():
+    """A one-field run with a turbulence grid that reaches beyond the outer end of the transport grid
+    (tango/interfacegrids_gene.py:367-417): transport grid 0..0.8 (N=100), turbulence grid 0.1..1 (N=280), Shestakov
+    flux on the turbulence grid; and the profile map alone for a profile whose continuation turns negative."""
+    from tango import interfacegrids_gene as ig
+    N, NG = 100, 280
+    x = np.linspace(0, 0.8, N)
+    xg = np.linspace(0.1, 1.0, NG); dxg = xg[1] - xg[0]
+    th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
+    lm = lodestro_method.lm(0.3, 1.0, th)
+    mapper = ig.GridInterfaceTangoInside(x, xg)
+    f0 = multifield.Field(label='n', rightBC=0.25, profile_mminus1=1 - 0.9 * x, compute_all_H=ComputeAllH1F(1.0, 0.3),
+                          gridMapper=mapper, lodestroMethod=lm)
+    multifield.check_fields_initialize([f0])
+    call = multifield.ComputeAllHAllFields([f0], lodestro_method.TurbulenceHandler(dxg, x, shest.AnalyticFluxModel(dxg)))
+    s = tsolver.Solver(0.8, x, np.array([0, 0.5]), 25, 1e-14, call, [f0])
+    s.take_timestep()
+    print('iterations', len(s.errHistoryFinal), 'last err', s.errHistoryFinal[-1])
+    steep = 2.0 - 2.4 * x
+    save('g20_gridmap_inside_run', run_N=N, run_NG=NG, run_err=s.errHistoryFinal.copy(), run_final=s.profiles['n'].copy(),
+         run_it2=s.profilesAllIterations['n'][2].copy(), run_DE=lm._EWMATurbD._yEWMA_lminus1.copy(),
+         run_uE=lm._EWMAProfile._yEWMA_lminus1.copy(), steep=steep, steep_on_G=mapper.map_profile_onto_turb_grid(steep))
+
+
 def run_ref_3f(N, nu0, BCs, a_turb, a_prof, tol, maxit, inner=0, dt=1e6, keep=(), ic=None, **solver_kw):
     dx = 1 / (N - 1); x = np.arange(N) * dx
     th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
@@ -608,6 +632,6 @@ def g11():
 
 
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18', 'g19']
+    which = sys.argv[2:] or ['g1', 'g2', 'g3', 'g4', 'g567', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18', 'g19', 'g20']
     for w in which:
         globals()[w]()

@@ -320,6 +320,46 @@ def test_solver_with_extrapolating_grid_mapper(tango, golden, tag, path):
     assert np.allclose(s.errHistoryFinal, g[tag + '_err'], rtol=2e-5, atol=1e-12)
 
 
+@pytest.mark.parametrize('path', ['pipeline', 'generic'])
+def test_solver_with_turbulence_grid_beyond_the_transport_grid(tango, golden, path):
+    """GridInterfaceTangoInside: the turbulence grid ends beyond the outer end of the transport grid and the profile is
+    continued there by the constrained regression line (on the pipeline: a fixed matrix over its last ten points).  The
+    reference's trajectory, and its map of a profile whose continuation turns negative (cut off at zero)."""
+    from tango_amd import _hip as H
+    g = golden('g20_gridmap_inside_run')
+    N, NG = int(g['run_N']), int(g['run_NG'])
+    x = np.linspace(0, 0.8, N)
+    xg = np.linspace(0.1, 1.0, NG); dxg = xg[1] - xg[0]
+    sh = tango.extras.shestakov_nonlinear_diffusion
+    mapper = tango.interfacegrids_gene.GridInterfaceTangoInside(x, xg)
+    lm = tango.lodestro_method.lm(0.3, 1.0, {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10})
+    cb = sh.ComputeAllH(1.0, 0.3)
+    if path == 'generic':
+        cb = (lambda inner: (lambda t, xx, p, HT: inner(t, xx, p, HT)))(cb)
+    f = tango.multifield.Field(label='n', rightBC=0.25, profile_mminus1=1 - 0.9 * x, compute_all_H=cb, gridMapper=mapper, lodestroMethod=lm)
+    tango.multifield.check_fields_initialize([f])
+    call = tango.multifield.ComputeAllHAllFields([f], tango.lodestro_method.TurbulenceHandler(dxg, x, sh.AnalyticFluxModel(dxg)))
+    s = tango.solver.Solver(0.8, x, np.array([0, 0.5]), 25, 1e-14, call, [f], detectStaticH=False, iterationsPerCheck=5)
+    assert (type(s._fused).__name__ == '_FusedMapped1F') == (path == 'pipeline')
+    s.take_timestep()
+    assert len(s.errHistoryFinal) == len(g['run_err'])
+    assert relerr(s.profilesAllIterations['n'][2], g['run_it2']) < 1e-10
+    assert relerr(s.profiles['n'], g['run_final']) < 1e-10
+    assert relerr(lm._EWMATurbD._yEWMA_lminus1, g['run_DE']) < 1e-10 and relerr(lm._EWMAProfile._yEWMA_lminus1, g['run_uE']) < 1e-10
+    assert np.allclose(s.errHistoryFinal, g['run_err'], rtol=2e-5, atol=1e-12)
+    if path == 'pipeline':
+        fu = s._fused
+        src = H.DeviceArray.from_host(g['steep'][None, :])
+        out = H.DeviceArray((1, NG), zero=True)
+        fu._resample(fu.xT, src, N, fu.xG, NG, fu.fwd_lo, fu.fwd_hi, fu.fwd_nonneg, out)
+        for z_lo, z_n, M, o_lo, rows in fu.fwd_zones:
+            H.check(H.lib.tg_zone_apply(src.ptr, 1, N, z_lo, z_n, M.ptr, out.ptr, NG, o_lo, rows, 1, H.stream()))
+        got = out.to_host()[0]
+        assert relerr(got, g['steep_on_G']) < 1e-12 and got.min() == 0.0 and np.count_nonzero(got == 0.0) == np.count_nonzero(g['steep_on_G'] == 0.0)
+    else:
+        assert relerr(mapper.map_profile_onto_turb_grid(g['steep']), g['steep_on_G']) < 1e-12
+
+
 def test_grid_mapper_pipeline_ensemble(tango):
     """The device-resident mapped pipeline on an ensemble whose members stop on their own iterations, member by member against
     the same run on the generic path (same kernels for every map, host arrays in between)."""
