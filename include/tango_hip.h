@@ -134,12 +134,14 @@ int tg_moving_average(const double *x, int window, double *out, int64_t nb, int6
  * xout[out_lo:out_hi]; the other entries of yout (nb, nout) are set to zero (a coefficient extended with zeros onto
  * a larger grid); nonneg != 0 replaces negative values by zero (enforcePositive).  Points of xout outside xin
  * continue the end cubics, as the reference's spline does. */
-/* out[b, out_lo + r] = sum_{z < zone} M[r * zone + z] * in[b, in_lo + z] for r < rows (clipped at zero from below when
- * nonneg), the rest of out untouched: the polynomial extrapolation of the transport coefficients beyond the trusted part
- * of the turbulence grid (np.polyfit over the points of a zone + np.polyval beyond it, tango/interfacegrids_gene.py:288-292,
- * :349-360) as the fixed matrix it is, M = polyval(polyfit(x_zone, I)) built once on the host from the two grids. */
-int tg_zone_apply(const double *in, int64_t nb, int64_t nin, int64_t in_lo, int64_t zone, const double *M, double *out, int64_t nout,
-                  int64_t out_lo, int64_t rows, int nonneg, tg_stream stream);
+/* out[b, out_lo + r] = bias[r] + sum_{z < zone} M[r * zone + z] * in[b, in_lo + z] for r < rows (bias may be NULL; clipped at
+ * zero from below when nonneg), the rest of out untouched: the polynomial extrapolation of the transport coefficients beyond
+ * the trusted part of the turbulence grid (np.polyfit over the points of a zone + np.polyval beyond it,
+ * tango/interfacegrids_gene.py:288-292, :349-360) as the fixed matrix it is, M = polyval(polyfit(x_zone, I)) built once on the
+ * host from the two grids; likewise the straight-line continuations of a profile beyond the transport grid (:545-576 fitted
+ * slope: a matrix over the last ten points; :636-662 imposed slope: the end point plus bias = slope * (x - x_end)). */
+int tg_zone_apply(const double *in, int64_t nb, int64_t nin, int64_t in_lo, int64_t zone, const double *M, const double *bias, double *out,
+                  int64_t nout, int64_t out_lo, int64_t rows, int nonneg, tg_stream stream);
 
 size_t tg_spline_work_bytes(int64_t nb, int64_t nin);
 int tg_spline_resample(const double *xin, const double *yin, int64_t nb, int64_t nin, const double *xout, int64_t nout,

@@ -103,7 +103,7 @@ PROTOTYPES = {
     'tg_flux_split': (_int, [_p, _p, _dbl, _dbl, _dbl, _dbl, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     'tg_ddx': (_int, [_p, _dbl, _int, _p, _i64, _i64, _p]),
     'tg_moving_average': (_int, [_p, _int, _p, _i64, _i64, _p]),
-    'tg_zone_apply': (_int, [_p, _i64, _i64, _i64, _i64, _p, _p, _i64, _i64, _i64, _int, _p]),
+    'tg_zone_apply': (_int, [_p, _i64, _i64, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _int, _p]),
     'tg_tukey_window': (_int, [_p, _i64, _dbl, _p]),
     'tg_ar1_noise': (_int, [C.c_uint64, C.c_uint64, _dbl, _dbl, C.c_int32, _p, _p, _i64, _i64, _p]),
     'tg_shestakov_flux': (_int, [_p, _dbl, _p, _i64, _i64, _p]),

@@ -43,8 +43,8 @@ int main() {
     EXPECT(tg_ddx(dummy, 0.1, 3, dummy, 1, 4, nullptr) == TG_ERR_ARG);
     EXPECT(tg_ddx(dummy, 0.1, 2, dummy, 1, 2, nullptr) == TG_ERR_ARG);
     EXPECT(tg_moving_average(dummy, 4, dummy, 1, 8, nullptr) == TG_ERR_ARG);
-    EXPECT(tg_zone_apply(dummy, 1, 8, 4, 5, dummy, dummy, 8, 0, 2, 0, nullptr) == TG_ERR_ARG);
-    EXPECT(tg_zone_apply(nullptr, 1, 8, 0, 4, dummy, dummy, 8, 0, 2, 0, nullptr) == TG_ERR_ARG);
+    EXPECT(tg_zone_apply(dummy, 1, 8, 4, 5, dummy, nullptr, dummy, 8, 0, 2, 0, nullptr) == TG_ERR_ARG);
+    EXPECT(tg_zone_apply(nullptr, 1, 8, 0, 4, dummy, nullptr, dummy, 8, 0, 2, 0, nullptr) == TG_ERR_ARG);
     EXPECT(tg_moving_average(dummy, 9, dummy, 1, 8, nullptr) == TG_ERR_ARG);
     EXPECT(tg_spline_work_bytes(0, 10) == 0 && tg_spline_work_bytes(2, 3) == 0 && tg_spline_work_bytes(2, 10) >= 5 * 2 * 8 * sizeof(double));
     EXPECT(tg_spline_resample(dummy, dummy, 1, 3, dummy, 4, 0, 4, 0, dummy, dummy, 1 << 20, nullptr) == TG_ERR_ARG);

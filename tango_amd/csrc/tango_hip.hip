@@ -342,12 +342,14 @@ __global__ void moving_average_kernel(const double *__restrict__ x, int w, doubl
     }
 }
 
-// Part of a row as a fixed linear combination of a stretch of another row: out[b, out_lo + r] = sum_z M[r, z] in[b, in_lo + z].
+// Part of a row as a fixed affine map of a stretch of another row: out[b, out_lo + r] = bias[r] + sum_z M[r, z] in[b, in_lo + z]
+// (bias may be null).
 // The polynomial extrapolation of transport coefficients beyond the trusted part of a turbulence grid is such a map
 // (tango/interfacegrids_gene.py:288-292: a least-squares fit to the points of a zone, evaluated on the points beyond it,
 // is linear in the data and its matrix depends on the two grids only).  Summed left to right.
 __global__ void zone_apply_kernel(const double *__restrict__ in, int64_t nin, int64_t in_lo, int zone, const double *__restrict__ M,
-                                  double *__restrict__ out, int64_t nout, int64_t out_lo, int rows, int nonneg, int64_t nb) {
+                                  const double *__restrict__ bias, double *__restrict__ out, int64_t nout, int64_t out_lo, int rows,
+                                  int nonneg, int64_t nb) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = nb * rows, stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {
@@ -355,7 +357,7 @@ __global__ void zone_apply_kernel(const double *__restrict__ in, int64_t nin, in
         const int r = (int)(i - b * rows);
         const double *x = in + b * nin + in_lo;
         const double *m = M + (int64_t)r * zone;
-        double s = 0.0;
+        double s = bias ? bias[r] : 0.0;
         for (int z = 0; z < zone; ++z) s += m[z] * x[z];
         out[b * nout + out_lo + r] = (nonneg && s < 0.0) ? 0.0 : s;
     }
@@ -1568,15 +1570,15 @@ int tg_moving_average(const double *x, int window, double *out, int64_t nb, int6
     return launch_check();
 }
 
-int tg_zone_apply(const double *in, int64_t nb, int64_t nin, int64_t in_lo, int64_t zone, const double *M, double *out, int64_t nout,
-                  int64_t out_lo, int64_t rows, int nonneg, tg_stream stream) {
+int tg_zone_apply(const double *in, int64_t nb, int64_t nin, int64_t in_lo, int64_t zone, const double *M, const double *bias, double *out,
+                  int64_t nout, int64_t out_lo, int64_t rows, int nonneg, tg_stream stream) {
     if (!in || !M || !out) return fail(TG_ERR_ARG, "NULL array%s");
     if (nb < 0 || nin < 1 || nout < 1 || zone < 1 || zone > INT32_MAX || rows < 0 || rows > INT32_MAX || in_lo < 0 || in_lo + zone > nin || out_lo < 0 ||
         out_lo + rows > nout)
         return fail(TG_ERR_ARG, "zone or output range outside its row%s");
     if (nb == 0 || rows == 0) return TG_OK;
-    hipLaunchKernelGGL(zone_apply_kernel, dim3(grid_1d(nb * rows, 256)), dim3(256), 0, S(stream), in, nin, in_lo, (int)zone, M, out, nout, out_lo,
-                       (int)rows, nonneg, nb);
+    hipLaunchKernelGGL(zone_apply_kernel, dim3(grid_1d(nb * rows, 256)), dim3(256), 0, S(stream), in, nin, in_lo, (int)zone, M, bias, out, nout,
+                       out_lo, (int)rows, nonneg, nb);
     return launch_check();
 }
 

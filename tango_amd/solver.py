@@ -850,8 +850,8 @@ class _FusedMapped1F(_FusedExternal1F):
     """One field whose turbulence lives on a grid of its own (gridMapper = interfacegrids_gene.GridInterfaceTangoOutside,
     TangoOutsideExtrapCoeffs or TangoOutsideExtrapCoeffsBothSides: the transport grid reaches beyond the turbulence grid at
     both ends; the latter two replace the coefficients beyond the trusted part of the turbulence grid by a fitted polynomial;
-    or GridInterfaceTangoInside: the turbulence grid reaches beyond the outer end of the transport grid and the profile is
-    continued there by a fitted straight line).  Every step of tango/lodestro_method.py:327-388 stays
+    or GridInterfaceTangoInside / GridInterfaceTangoInsideFixedOutside: the turbulence grid reaches beyond the outer end of
+    the transport grid and the profile is continued there by a straight line of fitted or imposed slope).  Every step of tango/lodestro_method.py:327-388 stays
     on the device: spline of the profile onto the turbulence grid (tg_spline_resample), its EWMA (tg_ewma_profiles), the
     flux model (built-in Shestakov flux, a model on the GPU, or a Python model on the host through page-locked buffers),
     smoothing (tg_moving_average), the split (tg_flux_split), the EWMA of D and c on the turbulence grid, the spline of
@@ -868,7 +868,7 @@ class _FusedMapped1F(_FusedExternal1F):
         th = s.compute_all_H_all_fields.turbhandler
         m = f.lodestroMethod
         if type(f.gridMapper) not in (_ig.GridInterfaceTangoOutside, _ig.TangoOutsideExtrapCoeffs, _ig.TangoOutsideExtrapCoeffsBothSides,
-                                      _ig.GridInterfaceTangoInside) or type(m) is not _lm.lm:
+                                      _ig.GridInterfaceTangoInside, _ig.GridInterfaceTangoInsideFixedOutside) or type(m) is not _lm.lm:
             return None
         if m._fluxSplitter.ftheta != m._fluxSplitter._default_ftheta or f.coupledTo is not None:
             return None
@@ -919,8 +919,21 @@ class _FusedMapped1F(_FusedExternal1F):
         beyond the transport grid the stretches that continue the profile by the straight line through its last point with
         the least-squares slope of its last ten points (tango/interfacegrids_gene.py:545-604): that line is linear in the
         data, value(x) = y_last + (x - x_last) sum_z d_z (y_z - y_last) / sum_z d_z^2 with d_z = x_z - x_last, so it is
-        applied as a fixed matrix over those ten points."""
+        applied as a fixed matrix over those ten points.  Zones: (first input point, input points, matrix, first output point,
+        output points, bias or None)."""
         from . import interfacegrids_gene as _ig
+        D = H.DeviceArray
+        if type(mapper) is _ig.GridInterfaceTangoInsideFixedOutside:
+            # spline on the closed range of the transport grid, straight lines of the imposed slope through the end points
+            # outside it (:636-662): the end point's value plus slope * (x - x_end)
+            inside = np.flatnonzero((xG >= xT[0]) & (xG <= xT[-1]))
+            lo, hi = (int(inside[0]), int(inside[-1]) + 1) if inside.size else (0, 0)
+            zones = []
+            for out, end in ((np.arange(0, lo), 0), (np.arange(hi, xG.size), xT.size - 1)):
+                if out.size:
+                    bias = mapper.outwardSlopeGene * (xG[out] - xT[end])
+                    zones.append((end, 1, D.from_host(np.ones((out.size, 1))), int(out[0]), int(out.size), D.from_host(np.ascontiguousarray(bias))))
+            return lo, hi, True, zones
         if type(mapper) is not _ig.GridInterfaceTangoInside:
             return 0, xG.size, False, []
         inside = np.flatnonzero((xG > xT[0]) & (xG < xT[-1]))
@@ -933,7 +946,7 @@ class _FusedMapped1F(_FusedExternal1F):
             if out.size:
                 M = (xG[out] - xT[-1])[:, None] * w[None, :]
                 M[:, -1] += 1.0 - (xG[out] - xT[-1]) * w.sum()
-                zones.append((xT.size - pts, pts, H.DeviceArray.from_host(np.ascontiguousarray(M)), int(out[0]), int(out.size)))
+                zones.append((xT.size - pts, pts, D.from_host(np.ascontiguousarray(M)), int(out[0]), int(out.size), None))
         return lo, hi, True, zones
 
     @staticmethod
@@ -956,7 +969,7 @@ class _FusedMapped1F(_FusedExternal1F):
         if type(mapper) is _ig.GridInterfaceTangoOutside:
             # the transport points strictly inside the turbulence grid (tango/interfacegrids_gene.py:446-484)
             return int(np.where(xT > xG[0])[0][0]), int(np.where(xT < xG[-1])[0][-1]) + 1, []
-        if type(mapper) is _ig.GridInterfaceTangoInside:
+        if type(mapper) in (_ig.GridInterfaceTangoInside, _ig.GridInterfaceTangoInsideFixedOutside):
             # the transport points to the right of the first turbulence point (:486-526)
             return int(np.where(xT > xG[0])[0][0]), xT.size, []
         if type(mapper) is _ig.TangoOutsideExtrapCoeffs:
@@ -975,7 +988,7 @@ class _FusedMapped1F(_FusedExternal1F):
         """D or c from the turbulence grid onto the transport grid (tango/lodestro_method.py:372)."""
         self._resample(self.xG, src, self.nt, self.xT, self.n, self.lo, self.hi, nonneg, out)
         for z_lo, z_n, M, o_lo, rows in self.zones:
-            H.check(H.lib.tg_zone_apply(src.ptr, self.nb, self.nt, z_lo, z_n, M.ptr, out.ptr, self.n, o_lo, rows, int(nonneg), H.stream()))
+            H.check(H.lib.tg_zone_apply(src.ptr, self.nb, self.nt, z_lo, z_n, M.ptr, None, out.ptr, self.n, o_lo, rows, int(nonneg), H.stream()))
 
     def params(self, s):
         q = _FusedExternal1F.params(self, s)
@@ -1026,8 +1039,8 @@ class _FusedMapped1F(_FusedExternal1F):
                     self._verify_static(s)
                 # profile onto the turbulence grid and its EWMA there (tango/lodestro_method.py:344-345)
                 self._resample(self.xT, self.u, self.n, self.xG, self.nt, self.fwd_lo, self.fwd_hi, self.fwd_nonneg, self.pT)
-                for z_lo, z_n, M, o_lo, rows in self.fwd_zones:
-                    H.check(H.lib.tg_zone_apply(self.u.ptr, self.nb, self.n, z_lo, z_n, M.ptr, self.pT.ptr, self.nt, o_lo, rows,
+                for z_lo, z_n, M, o_lo, rows, bias in self.fwd_zones:
+                    H.check(H.lib.tg_zone_apply(self.u.ptr, self.nb, self.n, z_lo, z_n, M.ptr, H.ptr_of(bias), self.pT.ptr, self.nt, o_lo, rows,
                                                 int(self.fwd_nonneg), H.stream()))
                 H.check(H.lib.tg_ewma_profiles(self.pT.ptr, self.uE_t.ptr, float(a_prof), self.status.ptr, self.nb, self.nt, H.stream()))
                 # flux on the turbulence grid (:350), smoothing (:359-362)

@@ -516,7 +516,27 @@ def g20():
     s.take_timestep()
     print('iterations', len(s.errHistoryFinal), 'last err', s.errHistoryFinal[-1])
     steep = 2.0 - 2.4 * x
-    save('g20_gridmap_inside_run', run_N=N, run_NG=NG, run_err=s.errHistoryFinal.copy(), run_final=s.profiles['n'].copy(),
+    # the same problem with an imposed slope of the profile beyond the transport grid (:419-443); numpy.float as in g17
+    had = hasattr(np, 'float')
+    if not had:
+        np.float = float
+    try:
+        lm2 = lodestro_method.lm(0.3, 1.0, th)
+        mapper2 = ig.GridInterfaceTangoInsideFixedOutside(x, xg, -1.2)
+        f2 = multifield.Field(label='n', rightBC=0.25, profile_mminus1=1 - 0.9 * x, compute_all_H=ComputeAllH1F(1.0, 0.3),
+                              gridMapper=mapper2, lodestroMethod=lm2)
+        multifield.check_fields_initialize([f2])
+        call2 = multifield.ComputeAllHAllFields([f2], lodestro_method.TurbulenceHandler(dxg, x, shest.AnalyticFluxModel(dxg)))
+        s2 = tsolver.Solver(0.8, x, np.array([0, 0.5]), 25, 1e-14, call2, [f2])
+        s2.take_timestep()
+        print('fixed slope: iterations', len(s2.errHistoryFinal), 'last err', s2.errHistoryFinal[-1])
+        fixed = dict(fix_err=s2.errHistoryFinal.copy(), fix_final=s2.profiles['n'].copy(), fix_it2=s2.profilesAllIterations['n'][2].copy(),
+                     fix_DE=lm2._EWMATurbD._yEWMA_lminus1.copy(), fix_uE=lm2._EWMAProfile._yEWMA_lminus1.copy(),
+                     fix_steep_on_G=mapper2.map_profile_onto_turb_grid(steep))
+    finally:
+        if not had:
+            del np.float
+    save('g20_gridmap_inside_run', **fixed, run_N=N, run_NG=NG, run_err=s.errHistoryFinal.copy(), run_final=s.profiles['n'].copy(),
          run_it2=s.profilesAllIterations['n'][2].copy(), run_DE=lm._EWMATurbD._yEWMA_lminus1.copy(),
          run_uE=lm._EWMAProfile._yEWMA_lminus1.copy(), steep=steep, steep_on_G=mapper.map_profile_onto_turb_grid(steep))
 

@@ -282,7 +282,7 @@ def test_extrapolated_coefficients_on_the_device(tango, golden):
             H.check(H.lib.tg_spline_resample(xG_d.ptr, src_d.ptr, 2, xG.size, xT_d.ptr, xT.size, lo, hi, int(nonneg), out.ptr, work.ptr,
                                              work.nbytes, H.stream()))
             for z_lo, z_n, M, o_lo, rows in zones:
-                H.check(H.lib.tg_zone_apply(src_d.ptr, 2, xG.size, z_lo, z_n, M.ptr, out.ptr, xT.size, o_lo, rows, int(nonneg), H.stream()))
+                H.check(H.lib.tg_zone_apply(src_d.ptr, 2, xG.size, z_lo, z_n, M.ptr, None, out.ptr, xT.size, o_lo, rows, int(nonneg), H.stream()))
             got = out.to_host()
             assert relerr(got[0], ref) < 1e-12 and relerr(got[1], 0.5 * ref) < 1e-12
             if nonneg:
@@ -320,10 +320,12 @@ def test_solver_with_extrapolating_grid_mapper(tango, golden, tag, path):
     assert np.allclose(s.errHistoryFinal, g[tag + '_err'], rtol=2e-5, atol=1e-12)
 
 
+@pytest.mark.parametrize('slope', ['fitted', 'imposed'])
 @pytest.mark.parametrize('path', ['pipeline', 'generic'])
-def test_solver_with_turbulence_grid_beyond_the_transport_grid(tango, golden, path):
-    """GridInterfaceTangoInside: the turbulence grid ends beyond the outer end of the transport grid and the profile is
-    continued there by the constrained regression line (on the pipeline: a fixed matrix over its last ten points).  The
+def test_solver_with_turbulence_grid_beyond_the_transport_grid(tango, golden, path, slope):
+    """GridInterfaceTangoInside / ...FixedOutside: the turbulence grid ends beyond the outer end of the transport grid and the
+    profile is continued there by the constrained regression line (on the pipeline: a fixed matrix over its last ten points)
+    or by a line of imposed slope (the end point plus a fixed bias).  The
     reference's trajectory, and its map of a profile whose continuation turns negative (cut off at zero)."""
     from tango_amd import _hip as H
     g = golden('g20_gridmap_inside_run')
@@ -331,7 +333,9 @@ def test_solver_with_turbulence_grid_beyond_the_transport_grid(tango, golden, pa
     x = np.linspace(0, 0.8, N)
     xg = np.linspace(0.1, 1.0, NG); dxg = xg[1] - xg[0]
     sh = tango.extras.shestakov_nonlinear_diffusion
-    mapper = tango.interfacegrids_gene.GridInterfaceTangoInside(x, xg)
+    ig = tango.interfacegrids_gene
+    mapper = ig.GridInterfaceTangoInside(x, xg) if slope == 'fitted' else ig.GridInterfaceTangoInsideFixedOutside(x, xg, -1.2)
+    k = 'run_' if slope == 'fitted' else 'fix_'
     lm = tango.lodestro_method.lm(0.3, 1.0, {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10})
     cb = sh.ComputeAllH(1.0, 0.3)
     if path == 'generic':
@@ -342,22 +346,22 @@ def test_solver_with_turbulence_grid_beyond_the_transport_grid(tango, golden, pa
     s = tango.solver.Solver(0.8, x, np.array([0, 0.5]), 25, 1e-14, call, [f], detectStaticH=False, iterationsPerCheck=5)
     assert (type(s._fused).__name__ == '_FusedMapped1F') == (path == 'pipeline')
     s.take_timestep()
-    assert len(s.errHistoryFinal) == len(g['run_err'])
-    assert relerr(s.profilesAllIterations['n'][2], g['run_it2']) < 1e-10
-    assert relerr(s.profiles['n'], g['run_final']) < 1e-10
-    assert relerr(lm._EWMATurbD._yEWMA_lminus1, g['run_DE']) < 1e-10 and relerr(lm._EWMAProfile._yEWMA_lminus1, g['run_uE']) < 1e-10
-    assert np.allclose(s.errHistoryFinal, g['run_err'], rtol=2e-5, atol=1e-12)
+    assert len(s.errHistoryFinal) == len(g[k + 'err'])
+    assert relerr(s.profilesAllIterations['n'][2], g[k + 'it2']) < 1e-10
+    assert relerr(s.profiles['n'], g[k + 'final']) < 1e-10
+    assert relerr(lm._EWMATurbD._yEWMA_lminus1, g[k + 'DE']) < 1e-10 and relerr(lm._EWMAProfile._yEWMA_lminus1, g[k + 'uE']) < 1e-10
+    assert np.allclose(s.errHistoryFinal, g[k + 'err'], rtol=2e-5, atol=1e-12)
     if path == 'pipeline':
         fu = s._fused
         src = H.DeviceArray.from_host(g['steep'][None, :])
         out = H.DeviceArray((1, NG), zero=True)
         fu._resample(fu.xT, src, N, fu.xG, NG, fu.fwd_lo, fu.fwd_hi, fu.fwd_nonneg, out)
-        for z_lo, z_n, M, o_lo, rows in fu.fwd_zones:
-            H.check(H.lib.tg_zone_apply(src.ptr, 1, N, z_lo, z_n, M.ptr, out.ptr, NG, o_lo, rows, 1, H.stream()))
+        for z_lo, z_n, M, o_lo, rows, bias in fu.fwd_zones:
+            H.check(H.lib.tg_zone_apply(src.ptr, 1, N, z_lo, z_n, M.ptr, H.ptr_of(bias), out.ptr, NG, o_lo, rows, 1, H.stream()))
         got = out.to_host()[0]
-        assert relerr(got, g['steep_on_G']) < 1e-12 and got.min() == 0.0 and np.count_nonzero(got == 0.0) == np.count_nonzero(g['steep_on_G'] == 0.0)
+        assert relerr(got, g['steep_on_G' if slope == 'fitted' else 'fix_steep_on_G']) < 1e-12 and got.min() == 0.0 and np.count_nonzero(got == 0.0) == np.count_nonzero(g['steep_on_G' if slope == 'fitted' else 'fix_steep_on_G'] == 0.0)
     else:
-        assert relerr(mapper.map_profile_onto_turb_grid(g['steep']), g['steep_on_G']) < 1e-12
+        assert relerr(mapper.map_profile_onto_turb_grid(g['steep']), g['steep_on_G' if slope == 'fitted' else 'fix_steep_on_G']) < 1e-12
 
 
 def test_grid_mapper_pipeline_ensemble(tango):
