@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_header():
     """ctypes mirrors of the parameter structs have the size the C compiler gives them."""
-    import subprocess, tempfile, sys
+    import subprocess
+    import tempfile
     from tango_amd import _hip as H
     src = '#include <stdio.h>\n#include "tango_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu", sizeof(tg_hcoeffs), ' \
           'sizeof(tg_state_1f), sizeof(tg_params_1f), sizeof(tg_state_3f), sizeof(tg_params_3f));return 0;}\n'

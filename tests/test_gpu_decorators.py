@@ -1,7 +1,6 @@
 """Flux-model decorators and the generalised analytic flux on the device: the Tukey taper of tango/extras/bufferzone.py,
 the AR(1) multiplicative noise of tango/extras/noisyflux.py and the |n'/n|^p flux of
 examples/stripped_down_tango_example.py, as parts of the fused one-field step."""
-import ctypes as C
 
 import numpy as np
 import pytest

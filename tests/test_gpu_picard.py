@@ -1,7 +1,6 @@
 """The fused device-resident Picard step and the Solver on top of it, against reference trajectories (golden
 vectors), the CPU oracle, and size-independent properties at the benchmark's full size."""
 import os
-import ctypes as C
 
 import numpy as np
 import pytest
