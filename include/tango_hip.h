@@ -244,7 +244,7 @@ typedef struct {
     double tread_max_change;
     double tread_initial_dtau;
     /* Optional work space of tg_picard_1f_work_bytes(nb, n) bytes.  With it, profiles of n = 4096, 8192, 16384 or 32768
-     * points (built-in flux, Cartesian, no pseudo-timestep control) are stepped in segments of 512 points, one
+     * points (built-in flux, Cartesian) are stepped in segments of 512 points, one
      * wavefront each, in three kernels: turbulence update + assembly + elimination per segment; the reduced system
      * of the segment-lane unknowns per profile; back substitution per segment (with iters_per_launch > 1 the back
      * substitution of one iteration and the first kernel of the next are one kernel).  Without it (NULL) such
@@ -271,13 +271,20 @@ enum { TG_TREAD_MAX_HALVINGS = 64 };
 /* bytes of tg_params_1f.work that make the segmented form available for (nb, n); 0 where it does not apply
  * (tango/solver.py:188-272 has no counterpart of a work space: NumPy allocates its temporaries itself) */
 size_t tg_picard_1f_work_bytes(int64_t nb, int64_t n);
+/* the same for steps under pseudo-timestep control (pseudo_time set): room for the previous iterate on top.  With a work
+ * space of this size such profiles keep the segmented form: one iteration at a time (iters_per_launch > 1: that many in a
+ * row), tread_initial_* by a per-profile pseudo-timestep, tread_lightly by further attempts of the marked profiles with
+ * dtau/2, dtau/4, ... and the same D and c (tango/solver.py:361-371); the host reads one counter per attempt, so a call
+ * with tread_lightly returns with the stream drained.  With a smaller work space they take the workgroup kernel. */
+size_t tg_picard_1f_work_bytes_tread(int64_t nb, int64_t n);
 int tg_picard_1f_step(const tg_state_1f *state, const tg_params_1f *params, tg_stream stream);
 
 /* The same step for callers that cannot allocate device memory (code under HIP graph capture, serving loops,
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  It is tg_picard_1f_step for the profile
  * lengths whose step can use a work space (n = 4096, 8192, 16384, 32768; built-in flux, Cartesian),
  * with params->work ignored: the work space is a TG_STATIC_WORK_BYTES array inside the library, one per GPU, held
- * until the process ends.  tg_picard_1f_work_bytes(nb, n) must not exceed TG_STATIC_WORK_BYTES (about 4.7 million
+ * until the process ends.  tg_picard_1f_work_bytes(nb, n) (with pseudo_time: tg_picard_1f_work_bytes_tread) must not exceed
+ * TG_STATIC_WORK_BYTES (about 4.7 million
  * grid points in all, e.g. 512 x 8192); larger ensembles get TG_ERR_ARG, other profile lengths TG_ERR_UNSUPPORTED
  * (they need no work space: tg_picard_1f_step allocates nothing for them either).  The call allocates and frees
  * nothing; the first call on a device looks up the array's address (make it outside graph capture).  All calls

@@ -91,6 +91,7 @@ PROTOTYPES = {
     'tg_stream_probe': (_int, [_p * 5, _p * 4, _i64, _p]),
     'tg_tridiag_work_bytes': (_sz, [_i64, _i64, _int]),
     'tg_picard_1f_work_bytes': (_sz, [_i64, _i64]),
+    'tg_picard_1f_work_bytes_tread': (_sz, [_i64, _i64]),
     'tg_spline_work_bytes': (_sz, [_i64, _i64]),
     'tg_spline_resample': (_int, [_p, _p, _i64, _i64, _p, _i64, _i64, _i64, _int, _p, _p, _sz, _p]),
     'tg_tridiag_solve': (_int, [_p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _sz, _p]),

@@ -1635,6 +1635,7 @@ int tg_shestakov_flux(const double *nprof, double dx, double *flux, int64_t nb, 
 }
 
 size_t tg_picard_1f_work_bytes(int64_t nb, int64_t n) { return (nb > 0 && n > 0) ? tg_seg_work_bytes(nb, n) : 0; }
+size_t tg_picard_1f_work_bytes_tread(int64_t nb, int64_t n) { return (nb > 0 && n > 0) ? tg_seg_work_bytes_tread(nb, n) : 0; }
 
 int tg_picard_1f_step(const tg_state_1f *st, const tg_params_1f *q, tg_stream stream) {
     if (int e = tg_picard_1f_validate(st, q)) return e;

@@ -37,6 +37,11 @@ using namespace tg;
 constexpr int kSeg = 512;        // points per segment = 64 lanes x 8 points
 constexpr int kRowQ = 4;         // doubles a lane leaves for the reduced system
 constexpr int kHaloQ = 12;       // doubles kept per segment boundary
+// what a launch of the segment kernels is: an ordinary iteration; the first attempt of an iteration under pseudo-timestep
+// control (the new iterate is tentative: no verdict on its validity yet); a further attempt with half the pseudo-timestep for
+// the profiles marked in SegWork::redo (same D and c, no bookkeeping: iteration count, residual and convergence were the
+// first attempt's business)
+constexpr int kPlain = 0, kFirstAttempt = 1, kRetry = 2;
 
 // work space layout (all double unless noted), L = nb n / 8 lanes, S = n / 512 segments per profile
 struct SegWork {
@@ -51,11 +56,20 @@ struct SegWork {
                           // j = 512 (k+1); then, between two iterations of one call, the new profile at j-2 .. j+1
     int32_t *flag;        // (nb,) 0: not stepped in this iteration, 1: stepped, 2: stepped and converged
     int32_t *sing;        // (nb,) zero pivot met somewhere
+    // pseudo-timestep control
+    double *dtau;         // (nb,) pseudo-timestep of the profile's current attempt
+    int32_t *redo;        // (nb,) the last attempt moved the profile too far: another one with half the pseudo-timestep
+    int32_t *attempts;    // (nb,) halvings so far in this iteration
+    int32_t *nredo;       // (1,) profiles marked in redo by the last check
+    double *uprev;        // (nb n) the previous iterate, only in a work space of tg_picard_1f_work_bytes_tread
 };
+
+size_t seg_work_bytes(int64_t nb, int64_t n);
+size_t seg_work_bytes_tread(int64_t nb, int64_t n) { return seg_work_bytes(nb, n) + (((size_t)nb * (size_t)n * sizeof(double) + 255) & ~(size_t)255); }
 
 size_t seg_work_bytes(int64_t nb, int64_t n) {
     const int64_t L = nb * n / 8, S = n / kSeg;
-    size_t b = sizeof(double) * (size_t)((kRowQ + 1) * L + 5 * nb * S + kHaloQ * nb * (S - 1)) + sizeof(int32_t) * (size_t)(2 * nb);
+    size_t b = sizeof(double) * (size_t)((kRowQ + 1) * L + 5 * nb * S + kHaloQ * nb * (S - 1)) + sizeof(double) * (size_t)nb + sizeof(int32_t) * (size_t)(4 * nb + 4);
     return (b + 255) & ~(size_t)255;
 }
 
@@ -69,8 +83,13 @@ SegWork seg_carve(void *work, int64_t nb, int64_t n) {
     W.mx = p; p += nb * S;
     W.halo = p; p += kHaloQ * nb * (S - 1);
     W.first = p; p += 3 * nb * S;
+    W.dtau = p; p += nb;
     W.flag = reinterpret_cast<int32_t *>(p);
     W.sing = W.flag + nb;
+    W.redo = W.sing + nb;
+    W.attempts = W.redo + nb;
+    W.nredo = W.attempts + nb;
+    W.uprev = reinterpret_cast<double *>(static_cast<char *>(work) + seg_work_bytes(nb, n));
     return W;
 }
 
@@ -199,7 +218,7 @@ __device__ __forceinline__ void boundary_next_profile(const tg_state_1f &S_, con
 // registers, and with them at two per SIMD it measured 17 % faster than with 168 and 48 of them spilled
 template <int PHASE>
 __global__ void __launch_bounds__(256, PHASE == 0 ? 3 : (PHASE == 1 ? 4 : 2))
-picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
+picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
     extern __shared__ double lds[];
     using G = WaveGroup<64>;
     constexpr int P = 8;
@@ -215,7 +234,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
     const int st = S_.status[b];
     int flag = 1;
     if (PHASE == 0) {
-        if (!Q.fixed_count && (st & (TG_ST_CONVERGED | TG_ST_INVALID))) return;
+        if (mode == kRetry ? !W.redo[b] : (!Q.fixed_count && (st & (TG_ST_CONVERGED | TG_ST_INVALID)))) return;
     } else {
         flag = W.flag[b];
         if (flag == 0) return;
@@ -350,11 +369,14 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
         Tile::sync();
         wt.flush(0, S_.u + woff);
         if (t == 0) {
-            int bits = bad ? TG_ST_INVALID : 0;
+            // under pseudo-timestep control the iterate is tentative: seg_tread_check_kernel judges the one that stays
+            int bits = (bad && mode == kPlain) ? TG_ST_INVALID : 0;
             if (s == 0) {
-                S_.iters[b] += 1;
-                if (turb) bits |= TG_ST_SEEDED;
-                if (flag == 2) bits |= TG_ST_CONVERGED;
+                if (mode != kRetry) {
+                    S_.iters[b] += 1;
+                    if (turb) bits |= TG_ST_SEEDED;
+                    if (flag == 2) bits |= TG_ST_CONVERGED;
+                }
                 if (W.sing[b]) bits |= TG_ST_SINGULAR;
             }
             if (bits) atomicOr(&S_.status[b], bits);
@@ -497,11 +519,59 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Pseudo-timestep control (tango/solver.py:198-216, :311-402, :564-595) around the three kernels.  The previous iterate
+// sits in the u_{m-1} array (the caller's array: under pseudo_time it has no other use), the pseudo-timestep of every
+// profile in SegWork::dtau.
+// ------------------------------------------------------------------------------------------
+__global__ void seg_tread_init_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) *W.nredo = 0;
+    if (b >= S_.nb) return;
+    const double dt = Q.dt_b ? Q.dt_b[b] : Q.dt;
+    // treadInitially: a short pseudo-timestep for a profile's first iterations (:210-215)
+    W.dtau[b] = (S_.iters[b] < Q.tread_initial_steps) ? Q.tread_initial_dtau : dt;
+    W.attempts[b] = 0;
+    W.redo[b] = 0;
+}
+
+// After an attempt: did the new iterate (in u) move too far from the previous one (in u_{m-1}) somewhere in the inner
+// part of the profile?  Then the profile is marked for another attempt with half the pseudo-timestep, up to
+// TG_TREAD_MAX_HALVINGS of them; otherwise the iterate stays and gets its verdict (valid: finite and non-negative).
+// One workgroup per profile.
+__global__ void __launch_bounds__(256) seg_tread_check_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W) {
+    const int64_t b = blockIdx.x;
+    if (W.flag[b] == 0) return;                 // not stepped by the attempt that just ran
+    const double *u = S_.u + b * S_.n, *up = S_.um1 + b * S_.n;
+    int far = 0, bad = 0;
+    for (int j = threadIdx.x; j < (int)S_.n; j += blockDim.x) {
+        const double x = u[j], x0 = up[j];
+        far |= (j < Q.tread_inner_count) && (fabs((x - x0) / x0) >= Q.tread_max_change);
+        bad |= !(isfinite(x) && x >= 0.0);
+    }
+    const int both = __syncthreads_or(far | (bad << 1));
+    if (threadIdx.x != 0) return;
+    far = both & 1;
+    bad = both >> 1;
+    const int a = W.attempts[b];
+    if (far && a < TG_TREAD_MAX_HALVINGS) {
+        // dt/2, dt/4, ... of the full timestep, whatever the first attempt used (tango/solver.py:361-371)
+        W.dtau[b] = ldexp(Q.dt_b ? Q.dt_b[b] : Q.dt, -(a + 1));
+        W.attempts[b] = a + 1;
+        W.redo[b] = 1;
+        atomicAdd(W.nredo, 1);
+    } else {
+        W.redo[b] = 0;
+        const int bits = (bad ? TG_ST_INVALID : 0) | (far ? TG_ST_TREAD_LIMIT : 0);
+        if (bits) atomicOr(&S_.status[b], bits);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // the reduced system of one profile: n/8 rows, one workgroup of n/64 threads with 8 rows each
 // ------------------------------------------------------------------------------------------
 template <class G>
 __global__ void __launch_bounds__(G::T)
-picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next) {
+picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next, int mode) {
     extern __shared__ double lds[];
     constexpr int P = 8;
     G g(lds);
@@ -510,7 +580,7 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next) {
     const int S = n / kSeg;
     const int rows = n / 8;
     const int st = S_.status[b];
-    const bool active = Q.fixed_count || !(st & (TG_ST_CONVERGED | TG_ST_INVALID));
+    const bool active = (mode == kRetry) ? (W.redo[b] != 0) : (Q.fixed_count || !(st & (TG_ST_CONVERGED | TG_ST_INVALID)));
     if (!active) {
         if (g.t() == 0) W.flag[b] = 0;
         return;
@@ -565,10 +635,14 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next) {
             ss += W.ss[b * S + s];
             mx = fmax(mx, W.mx[b * S + s]);
         }
-        const double rms = sqrt(1.0 / (double)n * (ss / (mx * mx)));
-        const int it0 = S_.iters[b];
-        if (S_.err && it0 < S_.err_stride) S_.err[b * S_.err_stride + it0] = rms;
-        W.flag[b] = (!Q.fixed_count && rms < Q.tol) ? 2 : 1;
+        if (mode == kRetry) {       // the first attempt's matrix decided about convergence (tango/solver.py:464-470)
+            W.flag[b] = 1;
+        } else {
+            const double rms = sqrt(1.0 / (double)n * (ss / (mx * mx)));
+            const int it0 = S_.iters[b];
+            if (S_.err && it0 < S_.err_stride) S_.err[b * S_.err_stride + it0] = rms;
+            W.flag[b] = (!Q.fixed_count && rms < Q.tol) ? 2 : 1;
+        }
         if (sing) W.sing[b] = 1;
     }
 }
@@ -576,6 +650,11 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next) {
 }  // namespace
 
 // entry points for tango_hip.hip (C++ linkage: not part of the C ABI)
+size_t tg_seg_work_bytes_tread(int64_t nb, int64_t n) {
+    if (n != 4096 && n != 8192 && n != 16384 && n != 32768) return 0;
+    return seg_work_bytes_tread(nb, n);
+}
+
 size_t tg_seg_work_bytes(int64_t nb, int64_t n) {
     if (n != 4096 && n != 8192 && n != 16384 && n != 32768) return 0;      // n/64 threads solve the reduced system: a power of two
     return seg_work_bytes(nb, n);
@@ -583,7 +662,8 @@ size_t tg_seg_work_bytes(int64_t nb, int64_t n) {
 
 bool tg_seg_applies(const tg_state_1f *st, const tg_params_1f *q) {
     if (!q->work || tg_seg_work_bytes(st->nb, st->n) == 0 || q->work_bytes < tg_seg_work_bytes(st->nb, st->n)) return false;
-    if (q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly ||
+    if (q->pseudo_time && q->work_bytes < tg_seg_work_bytes_tread(st->nb, st->n)) return false;      // no room for the previous iterate
+    if (q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || (q->tread_lightly && !q->pseudo_time) ||
         q->smooth_window > 1 || q->iterates || q->flux_mult)
         return false;
     uintptr_t al = reinterpret_cast<uintptr_t>(st->u) | reinterpret_cast<uintptr_t>(st->um1) | reinterpret_cast<uintptr_t>(st->uE) |
@@ -605,25 +685,63 @@ int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
     const size_t lds_r = sizeof(double) * 8 * (size_t)lanes;
     if (lanes != 64 && lanes != 128 && lanes != 256 && lanes != 512) return fail(TG_ERR_UNSUPPORTED, "segmented form: n must be 4096, 8192, 16384 or 32768%s");
     const size_t lds_n = lds_r + sizeof(double) * (size_t)(n / 8);       // + the lane unknowns of the profile
-    auto reduce = [&](int next) {
+    auto reduce = [&](const tg_state_1f &state, const tg_params_1f &p, int next, int mode) {
         const size_t l = next ? lds_n : lds_r;
         switch (lanes) {
-        case 64: hipLaunchKernelGGL((picard_seg_reduce_kernel<WaveGroup<64>>), dim3((unsigned)nb), dim3(64), l, s, *st, *q, W, next); break;
-        case 128: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<128>>), dim3((unsigned)nb), dim3(128), l, s, *st, *q, W, next); break;
-        case 256: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<256>>), dim3((unsigned)nb), dim3(256), l, s, *st, *q, W, next); break;
-        default: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<512>>), dim3((unsigned)nb), dim3(512), l, s, *st, *q, W, next); break;
+        case 64: hipLaunchKernelGGL((picard_seg_reduce_kernel<WaveGroup<64>>), dim3((unsigned)nb), dim3(64), l, s, state, p, W, next, mode); break;
+        case 128: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<128>>), dim3((unsigned)nb), dim3(128), l, s, state, p, W, next, mode); break;
+        case 256: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<256>>), dim3((unsigned)nb), dim3(256), l, s, state, p, W, next, mode); break;
+        default: hipLaunchKernelGGL((picard_seg_reduce_kernel<BlockGroup<512>>), dim3((unsigned)nb), dim3(512), l, s, state, p, W, next, mode); break;
         }
     };
-    // iterations of one call: first half, reduce, then (second half + next first half), reduce, ... and the last second half
+    const dim3 hgrid((unsigned)((bounds + 255) / 256));
     const int iters = q->iters_per_launch > 1 ? q->iters_per_launch : 1;
-    hipLaunchKernelGGL(seg_halo_kernel, dim3((unsigned)((bounds + 255) / 256)), dim3(256), 0, s, *st, W);
-    hipLaunchKernelGGL((picard_seg_kernel<0>), dim3(grid), dim3(256), lds0, s, *st, *q, W);
-    for (int k = 1; k < iters; ++k) {
-        reduce(1);
-        hipLaunchKernelGGL((picard_seg_kernel<2>), dim3(grid), dim3(256), lds0, s, *st, *q, W);
+    if (q->pseudo_time) {
+        // Pseudo-timestep control: one iteration at a time.  The previous iterate and the profiles' pseudo-timesteps go
+        // into the work space; with tread_lightly every attempt is followed by a check, and while the
+        // check marks profiles the host queues another attempt for them: it reads one counter per attempt, so that a call
+        // with tread_lightly returns with the stream drained (the one exception to "every call is asynchronous").
+        tg_params_1f p = *q;
+        p.dt_b = W.dtau;
+        tg_state_1f sp = *st;
+        sp.um1 = W.uprev;
+        const int first = q->tread_lightly ? kFirstAttempt : kPlain;
+        const unsigned pgrid = (unsigned)((nb + 255) / 256);
+        for (int k = 0; k < iters; ++k) {
+            hipLaunchKernelGGL(seg_tread_init_kernel, dim3(pgrid), dim3(256), 0, s, *st, *q, W);
+            TG_HIP(hipMemcpyAsync(W.uprev, st->u, sizeof(double) * (size_t)nb * (size_t)n, hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(seg_halo_kernel, hgrid, dim3(256), 0, s, sp, W);
+            hipLaunchKernelGGL((picard_seg_kernel<0>), dim3(grid), dim3(256), lds0, s, sp, p, W, first);
+            reduce(sp, p, 0, first);
+            hipLaunchKernelGGL((picard_seg_kernel<1>), dim3(grid), dim3(256), lds1, s, sp, p, W, first);
+            if (!q->tread_lightly) continue;
+            tg_params_1f r = p;
+            r.frozen_turb = 1;          // further attempts keep D and c (tango/solver.py:361-371)
+            for (int attempt = 0;; ++attempt) {
+                hipLaunchKernelGGL(seg_tread_check_kernel, dim3((unsigned)nb), dim3(256), 0, s, sp, *q, W);
+                int32_t marked = 0;
+                TG_HIP(hipMemcpyAsync(&marked, W.nredo, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                TG_HIP(hipStreamSynchronize(s));
+                if (marked == 0) break;
+                if (attempt > TG_TREAD_MAX_HALVINGS) return fail(TG_ERR_HIP, "segmented form: the halving loop did not end%s");
+                TG_HIP(hipMemsetAsync(W.nredo, 0, sizeof(int32_t), s));
+                hipLaunchKernelGGL(seg_halo_kernel, hgrid, dim3(256), 0, s, sp, W);      // the memories as they are now
+                hipLaunchKernelGGL((picard_seg_kernel<0>), dim3(grid), dim3(256), lds0, s, sp, r, W, kRetry);
+                reduce(sp, r, 0, kRetry);
+                hipLaunchKernelGGL((picard_seg_kernel<1>), dim3(grid), dim3(256), lds1, s, sp, r, W, kRetry);
+            }
+        }
+        return launch_check();
     }
-    reduce(0);
-    hipLaunchKernelGGL((picard_seg_kernel<1>), dim3(grid), dim3(256), lds1, s, *st, *q, W);
+    // iterations of one call: first half, reduce, then (second half + next first half), reduce, ... and the last second half
+    hipLaunchKernelGGL(seg_halo_kernel, hgrid, dim3(256), 0, s, *st, W);
+    hipLaunchKernelGGL((picard_seg_kernel<0>), dim3(grid), dim3(256), lds0, s, *st, *q, W, kPlain);
+    for (int k = 1; k < iters; ++k) {
+        reduce(*st, *q, 1, kPlain);
+        hipLaunchKernelGGL((picard_seg_kernel<2>), dim3(grid), dim3(256), lds0, s, *st, *q, W, kPlain);
+    }
+    reduce(*st, *q, 0, kPlain);
+    hipLaunchKernelGGL((picard_seg_kernel<1>), dim3(grid), dim3(256), lds1, s, *st, *q, W, kPlain);
     return launch_check();
 }
 
@@ -658,7 +776,7 @@ int scratch_on_current_device(void **out) {
 
 extern "C" int tg_picard_1f_step_static(const tg_state_1f *st, const tg_params_1f *q, tg_stream stream) {
     if (int e = tg_picard_1f_validate(st, q)) return e;
-    const size_t need = tg_seg_work_bytes(st->nb, st->n);
+    const size_t need = q->pseudo_time ? tg_seg_work_bytes_tread(st->nb, st->n) : tg_seg_work_bytes(st->nb, st->n);
     if (need == 0) return fail(TG_ERR_UNSUPPORTED, "tg_picard_1f_step_static steps profiles of 4096, 8192, 16384 or 32768 points (the sizes "
                                                    "whose step uses a work space); other sizes need none: call tg_picard_1f_step%s");
     if (need > (size_t)TG_STATIC_WORK_BYTES)
@@ -672,6 +790,6 @@ extern "C" int tg_picard_1f_step_static(const tg_state_1f *st, const tg_params_1
     p.work_bytes = TG_STATIC_WORK_BYTES;
     if (!tg_seg_applies(st, &p))
         return fail(TG_ERR_UNSUPPORTED, "tg_picard_1f_step_static: the segmented step needs the built-in flux, Cartesian geometry, one "
-                                        "no pseudo-timestep control, no iterate history and 16-byte aligned arrays%s");
+                                        "no iterate history and 16-byte aligned arrays%s");
     return tg_seg_step(st, &p, S(stream));
 }

@@ -10,6 +10,7 @@ extern thread_local char tg_err_buf[512];
 
 // segmented form of the one-field step for long profiles (tango_seg.hip)
 size_t tg_seg_work_bytes(int64_t nb, int64_t n);
+size_t tg_seg_work_bytes_tread(int64_t nb, int64_t n);
 bool tg_seg_applies(const tg_state_1f *st, const tg_params_1f *q);
 int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s);
 // argument checks and the non-segmented launch of the one-field step (tango_hip.hip)

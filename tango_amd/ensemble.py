@@ -128,15 +128,16 @@ class OneFieldEnsemble:
     data_ptr() lets a caller own the memory (bench.py passes a torch allocator); default: tg_malloc."""
 
     def __init__(self, ens, dt=1e4, a_turb=0.3, a_prof=1.0, tol=1e-11, theta=THETA_DEFAULT, max_iter=1000,
-                 fixed_count=False, keep_err=True, alloc=None, segmented=True):
+                 fixed_count=False, keep_err=True, alloc=None, segmented=True, tread=False):
         u0 = np.ascontiguousarray(ens['u0'], dtype=np.float64)
         self.nb, self.n = nb, n = u0.shape
         f8, i4, i8 = np.float64, np.int32, np.int64
         plan = [((nb, n), f8)] * 5 + [((nb,), i4)] * 3 + [((nb,), f8)] * 2 + [((4,), i8)]
         if keep_err:
             plan.append(((nb, max_iter), f8))
-        # work space of the segmented form of the step (profiles of 8192 points and more), 0 bytes otherwise
-        work_bytes = int(H.lib.tg_picard_1f_work_bytes(nb, n)) if segmented else 0
+        # work space of the segmented form of the step (profiles of 4096 points and more), 0 bytes otherwise
+        # (tread: with room for the previous iterate, for steps under pseudo-timestep control)
+        work_bytes = int((H.lib.tg_picard_1f_work_bytes_tread if tread else H.lib.tg_picard_1f_work_bytes)(nb, n)) if segmented else 0
         if work_bytes:
             plan.append(((work_bytes // 8,), f8))
         self.pool = pool = Pool(Pool.size_for(plan), alloc)

@@ -532,7 +532,9 @@ class _Fused1F(object):
             self.status.set(np.full((nb,), H.ST_SEEDED, np.int32))
         self.state = H.State1F(nb, self.n, self.u.ptr, self.um1.ptr, self.uE.ptr, self.DE.ptr, self.cE.ptr,
                                self.status.ptr, self.iters.ptr, self.err.ptr, s.maxIterations)
-        wb = int(H.lib.tg_picard_1f_work_bytes(nb, self.n))      # segmented form of the step for long profiles
+        # segmented form of the step for long profiles; under pseudo-timestep control with room for the previous iterate
+        sized = H.lib.tg_picard_1f_work_bytes_tread if (s.useTreadLightly or s.useTreadInitially) else H.lib.tg_picard_1f_work_bytes
+        wb = int(sized(nb, self.n))
         self.work = H.DeviceArray((wb // 8,)) if wb else None
 
     def params(self, s):

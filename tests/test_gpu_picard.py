@@ -760,6 +760,57 @@ def test_segmented_multi_iteration_launch_equals_single_launches(tango, N, nb):
             assert np.array_equal(y.to_host(), x.to_host())
 
 
+@pytest.mark.parametrize('N', [4096, 8192])
+@pytest.mark.parametrize('case', ['initially', 'lightly', 'both'])
+def test_segmented_pseudo_timestep_control(tango, N, case):
+    """Pseudo-timestep control on long profiles: the segmented form (previous iterate and per-profile pseudo-timesteps in
+    the work space, further attempts of the marked profiles as extra rounds of the three kernels) against the
+    one-workgroup-per-profile kernel, which runs the halving loop inside the launch, and one member against the CPU
+    oracle."""
+    from oracle import tango_oracle as orc
+    from tango_amd.ensemble import OneFieldEnsemble
+    x = np.arange(N) * (1 / (N - 1)); dx = 1 / (N - 1)
+    ics = np.stack([-0.2 * (x - 1) + 1.2, 1.5 - 0.5 * x, 1.0 + 0.3 * np.cos(3 * x), 2.0 - x])
+    nb, its = len(ics), 14
+    ens = dict(x=x, dx=dx, u0=ics, nL=np.full(nb, 1.0), S0=np.full(nb, 1.0), delta=np.full(nb, 0.1))
+    lightly = dict(maxFractionalChange=0.08) if case in ('lightly', 'both') else None
+    initially = dict(numInitialSteps=5, dtau=0.4) if case in ('initially', 'both') else None
+    runs = []
+    for segmented in (False, True):
+        E = OneFieldEnsemble(ens, a_turb=0.1, a_prof=1.0, tol=1e-30, max_iter=its, segmented=segmented, tread=True)
+        q = E.params
+        q.pseudo_time = 1
+        if lightly:
+            q.tread_lightly, q.tread_max_change, q.tread_inner_count = 1, lightly['maxFractionalChange'], int(0.8 * N)
+        if initially:
+            q.tread_initial_steps, q.tread_initial_dtau = initially['numInitialSteps'], initially['dtau']
+        assert (E.work is not None) == segmented
+        for k in (1, 3, 1, 4, 5):
+            E.step(iters=k)
+        runs.append(E)
+    A, B = runs
+    assert np.array_equal(A.iters.to_host(), B.iters.to_host()) and np.all(A.iters.to_host() == its)
+    assert np.array_equal(A.status.to_host(), B.status.to_host()) and not np.any(B.status.to_host() & (2 | 4 | 16))
+    # The cosine-shaped member amplifies rounding differences on these grids in every implementation (it overshoots
+    # violently without the acceptance test and needs 150 halvings with it; measured against the oracle at N = 8192: 7e-8 for
+    # the workgroup kernel, 6e-8 for the segmented form, against 1e-11 .. 1e-10 for the other members): it runs along, so
+    # that profiles of one launch take very different numbers of attempts, but is not compared.
+    keep = [0, 1, 3]
+    # profiles to 5e-10 (measured 4e-12 .. 6e-11); D ~ (u'/u)^2 of these gently sloped profiles (u'/u ~ 0.3) amplifies the
+    # point-to-point rounding noise of two elimination orders by 2 / (dx u'/u) ~ 3e4 .. 5e4: measured 2e-9
+    for a, b, bar in ((A.u, B.u, 5e-10), (A.uE, B.uE, 5e-10), (A.DE, B.DE, 5e-8), (A.cE, B.cE, 5e-8)):
+        assert relerr(b.to_host()[keep], a.to_host()[keep]) < bar
+    assert np.allclose(A.err.to_host()[keep], B.err.to_host()[keep], rtol=1e-5, atol=1e-11)
+    # member 0 against the oracle's restatement of the reference loop (tango/solver.py:188-272, :311-402)
+    H7 = orc.shestakov_source(x, 1.0, 0.1)
+    tl = dict(lightly, innerFraction=0.8) if lightly else None
+    u, it, err, hist, halv = orc.run_1f_tread(ics[0], 1e4, dx, 1.0, np.ones(N), H7, 0.1, 1.0, 1e-30, its, tl, initially)
+    assert relerr(B.u.to_host()[0], u) < 5e-10
+    assert np.allclose(B.err.to_host()[0, :its], err, rtol=1e-5, atol=1e-11)
+    if lightly:
+        assert halv.sum() > 10          # the case really halved, many times
+
+
 def test_flux_model_on_the_device():
     """A flux model that lives on the GPU (tests/device_flux_case.py).  In a process of its own: torch brings its own
     HIP runtime, which has to be loaded before libtango_hip.so for the two to share it, and this test session has

@@ -9,14 +9,19 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(nb, n, its, static):
+def _run(nb, n, its, static, tread=False):
     from tango_amd import _hip as H
     from tango_amd.ensemble import OneFieldEnsemble, shestakov_ensemble
-    E = OneFieldEnsemble(shestakov_ensemble(nb, n), a_turb=0.3, a_prof=0.3, tol=1e-9, max_iter=its, segmented=not static)
+    E = OneFieldEnsemble(shestakov_ensemble(nb, n), a_turb=0.3, a_prof=0.3, tol=1e-9, max_iter=its, segmented=not static, tread=tread)
+    if tread:       # pseudo-timestep control: short first steps, halving of steps that move the profile by 5 % or more
+        q = E.params
+        q.pseudo_time, q.tread_initial_steps, q.tread_initial_dtau = 1, 1, 0.5
+        q.tread_lightly, q.tread_max_change, q.tread_inner_count = 1, 0.05, n // 2
     if static:
         assert not E.params.work                 # no caller work space at all
     else:
-        assert E.params.work and E.params.work_bytes == H.lib.tg_picard_1f_work_bytes(nb, n)
+        sized = H.lib.tg_picard_1f_work_bytes_tread if tread else H.lib.tg_picard_1f_work_bytes
+        assert E.params.work and E.params.work_bytes == sized(nb, n)
     fn = H.lib.tg_picard_1f_step_static if static else H.lib.tg_picard_1f_step
     for _ in range(its):
         H.check(fn(C.byref(E.state), C.byref(E.params), H.stream()))
@@ -33,6 +38,11 @@ def test_static_work_space_matches_caller_work_space():
         for k in ref:
             assert np.array_equal(got[k], ref[k]), (nb, n, k)
         assert np.all(got['iters'] == its) and np.all(np.isfinite(got['u'])) and not np.any(got['status'] & 6)
+    # under pseudo-timestep control the built-in array also holds the previous iterates
+    got, ref = _run(6, 4096, 3, static=True, tread=True), _run(6, 4096, 3, static=False, tread=True)
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.all(got['iters'] == 3) and not np.any(got['status'] & 6)
 
 
 def test_static_work_space_rejects_what_it_cannot_hold():
