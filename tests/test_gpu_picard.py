@@ -811,6 +811,30 @@ def test_segmented_pseudo_timestep_control(tango, N, case):
         assert halv.sum() > 10          # the case really halved, many times
 
 
+def test_solver_long_profiles_pseudo_timestep_control(tango):
+    """The same through Solver: a batched run of 4096-point profiles with useTreadLightly and useTreadInitially takes the
+    segmented form (work space sized for the previous iterate) and follows the reference loop as restated by the oracle."""
+    from oracle import tango_oracle as orc
+    N, its = 4096, 12
+    x = np.arange(N) * (1 / (N - 1)); dx = 1 / (N - 1)
+    ics = np.stack([-0.2 * (x - 1) + 1.2, 1.5 - 0.5 * x, 2.0 - x])
+    tl, ti = {'maxFractionalChange': 0.08, 'innerFraction': 0.8}, {'numInitialSteps': 3, 'dtau': 0.4}
+    s, lm = make_solver(tango, N, 1.0, 1.0, 0.1, ics, 0.1, 1.0, 1e-30, its, useTreadLightly=True, treadLightlyParams=tl,
+                        useTreadInitially=True, treadInitiallyParams=ti, iterationsPerCheck=5)
+    assert type(s._fused).__name__ == '_Fused1F' and s._fused.work is not None
+    assert s._fused.work.nbytes == tango._hip.lib.tg_picard_1f_work_bytes_tread(3, N)
+    s.take_timestep()
+    assert np.all(s.iterationsPerProfile == its) and not s.solutionError and not np.any(s.profileStatus & 16)
+    H7 = orc.shestakov_source(x, 1.0, 0.1)
+    total = 0
+    for b in range(3):
+        u, it, err, hist, halv = orc.run_1f_tread(ics[b], 1e4, dx, 1.0, np.ones(N), H7, 0.1, 1.0, 1e-30, its, tl, ti)
+        total += int(halv.sum())
+        assert relerr(s.profiles['n'][b], u) < 5e-10, b
+        assert np.allclose(s.errHistory[b, :its], err, rtol=1e-5, atol=1e-11), b
+    assert total > 20
+
+
 def test_flux_model_on_the_device():
     """A flux model that lives on the GPU (tests/device_flux_case.py).  In a process of its own: torch brings its own
     HIP runtime, which has to be loaded before libtango_hip.so for the two to share it, and this test session has
