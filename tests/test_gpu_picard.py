@@ -835,6 +835,45 @@ def test_solver_long_profiles_pseudo_timestep_control(tango):
     assert total > 20
 
 
+@pytest.mark.parametrize('N,k', [(500, 1), (512, 1), (512, 4), (1024, 1), (4096, 1), (4096, 3), (8192, 2)])
+def test_frozen_coefficients_one_field(tango, N, k):
+    """Iterations that reuse D and c as they are (frozen_turb: the inner iteration of tango/solver.py:274-309 for one field):
+    after three ordinary iterations, four with frozen coefficients, k per launch, on every form of the one-field step (one
+    wavefront, workgroup, segmented with one iteration per call and chained).  The memories must not move at all; profiles
+    and residuals against the oracle's pieces (assembly from the stored D and c, residual, solve)."""
+    from oracle import tango_oracle as orc
+    from tango_amd.ensemble import OneFieldEnsemble
+    nb = 3
+    ens = orc.shestakov_ensemble(nb, N)
+    E = OneFieldEnsemble(ens, a_prof=0.3, max_iter=16, fixed_count=True)
+    for _ in range(3):
+        E.step()
+    mem = [a.to_host() for a in (E.uE, E.DE, E.cE)]
+    u3 = E.u.to_host()
+    E.params.frozen_turb = 1
+    done = 0
+    while done < 4:
+        E.step(iters=min(k, 4 - done))
+        done += min(k, 4 - done)
+    assert np.all(E.iters.to_host() == 7) and not np.any(E.status.to_host() & 6)
+    for a, b in zip((E.uE, E.DE, E.cE), mem):
+        assert np.array_equal(a.to_host(), b)
+    H7 = orc.shestakov_source(ens['x'], ens['S0'], ens['delta'])
+    err = E.err.to_host()
+    bar = TOL if N <= 2048 else 3e-10
+    for b in range(nb):
+        u = u3[b]
+        H2, H3 = orc.dc_to_h(mem[1][b], mem[2][b])
+        A, B, C, f = orc.h_to_matrix(1e4, ens['dx'], ens['nL'][b], ens['u0'][b], np.ones(N), H2=H2, H3=H3, H7=H7[b])
+        for it in range(4):
+            rms = orc.rms_of([orc.residual(A, B, C, f, u)])
+            # for one field the frozen system is the one the last ordinary iteration solved: its own solution's residual,
+            # i.e. the rounding floor, in both codes (the mode earns its keep with coupled fields; here it is plumbing)
+            assert rms < 1e-8 and 0 < err[b, 3 + it] < 1e-8, (b, it)
+            u = orc.tridiag_solve(A, B, C, f)
+        assert relerr(E.u.to_host()[b], u) < bar, b
+
+
 def test_flux_model_on_the_device():
     """A flux model that lives on the GPU (tests/device_flux_case.py).  In a process of its own: torch brings its own
     HIP runtime, which has to be loaded before libtango_hip.so for the two to share it, and this test session has
