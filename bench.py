@@ -9,7 +9,7 @@ check) of every profile of the ensemble, all profiles forced active.  Configurat
   c2      one field, 65 536 x 256
   c3      three fields n, pi<->pe with nonlinear nu, 16 384 x 512, EWMA 0.3/0.3, dt = 1e6
   c4      one field, 4 096 x 8192, EWMA 0.3/0.3 (segmented form of the step)
---iters-per-launch k (one-field configurations up to 512 points; default 64 for metric and c2) runs k consecutive
+--iters-per-launch k (one-field configurations up to 2048 points; default 64 for metric and c2) runs k consecutive
 steps in one kernel launch with every profile held in registers in between: the arithmetic, the per-iteration
 convergence test and the residual history are those of k single launches, only the HBM round trip of the state
 between iterations is gone.  For c4 (default 16) the k iterations of a call are a chain of kernels in which the second
@@ -198,8 +198,8 @@ def main():
     per_gpu = args.profiles_per_gpu or per_gpu
     n = args.n or n
     kper = max(1, args.iters_per_launch or kdef)
-    if fields == 3 or 512 < n < 4096:
-        kper = 1                                   # these kernels run one iteration per launch
+    if fields == 3:
+        kper = 1                                   # the three-field kernel runs one iteration per launch
     check = max(kper, args.check_every - args.check_every % kper)
     k1_steps = max(8, args.steps // 4) if kper > 1 else 0
     rows = args.warmup + args.steps + k1_steps + 8  # residual history columns: every iteration of this run
