@@ -287,7 +287,7 @@ def main():
         bytes_per_iter = shard * n * bpp
         tag = f'{args.config}_{per_gpu}x{n}'
         hbm_k1 = None
-        segmented = fields == 1 and n >= 4096
+        segmented = fields == 1 and (n >= 8192 or (n == 4096 and kper == 1))
         if kper == 1 or segmented:
             # every iteration crosses HBM (the segmented form's k iterations per call are a chain of kernels)
             per_launch = args.steps / launches

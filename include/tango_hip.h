@@ -247,7 +247,8 @@ typedef struct {
      * points (built-in flux, Cartesian) are stepped in segments of 512 points, one
      * wavefront each, in three kernels: turbulence update + assembly + elimination per segment; the reduced system
      * of the segment-lane unknowns per profile; back substitution per segment (with iters_per_launch > 1 the back
-     * substitution of one iteration and the first kernel of the next are one kernel).  Without it (NULL) such
+     * substitution of one iteration and the first kernel of the next are one kernel; n = 4096 with iters_per_launch > 1
+     * takes the workgroup kernel, which then keeps the profile in registers and is faster).  Without it (NULL) such
      * profiles take the one-workgroup-per-profile kernel (n <= 16384), which is 2-4 times slower at those sizes. */
     void *work;
     size_t work_bytes;

@@ -663,6 +663,9 @@ size_t tg_seg_work_bytes(int64_t nb, int64_t n) {
 bool tg_seg_applies(const tg_state_1f *st, const tg_params_1f *q) {
     if (!q->work || tg_seg_work_bytes(st->nb, st->n) == 0 || q->work_bytes < tg_seg_work_bytes(st->nb, st->n)) return false;
     if (q->pseudo_time && q->work_bytes < tg_seg_work_bytes_tread(st->nb, st->n)) return false;      // no room for the previous iterate
+    // 4096 points still fit one workgroup with the profile held in registers between the iterations of a call: measured
+    // 0.34 ms per iteration at 16 per call against 0.53 for the chain of segment kernels (and 0.66 for either at one per call)
+    if (st->n == 4096 && q->iters_per_launch > 1 && !q->pseudo_time) return false;
     if (q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || (q->tread_lightly && !q->pseudo_time) ||
         q->smooth_window > 1 || q->iterates || q->flux_mult)
         return false;
