@@ -290,7 +290,8 @@ int tg_picard_1f_step(const tg_state_1f *state, const tg_params_1f *params, tg_s
  * (they need no work space: tg_picard_1f_step allocates nothing for them either).  The call allocates and frees
  * nothing; the first call on a device looks up the array's address (make it outside graph capture).  All calls
  * on one GPU share that array: calls that overlap in time on one GPU (different streams or threads) race; calls
- * ordered on one stream are safe, every call clears what it needs cleared. */
+ * ordered on one stream are safe, every call clears what it needs cleared.  With tread_lightly the call waits for the
+ * stream after every attempt (see tg_picard_1f_work_bytes_tread), which graph capture does not allow. */
 enum { TG_STATIC_WORK_BYTES = 24 * 1024 * 1024 };
 int tg_picard_1f_step_static(const tg_state_1f *state, const tg_params_1f *params, tg_stream stream);
 
