@@ -162,6 +162,8 @@ def main():
     ap.add_argument('--iters-per-launch', type=int, default=0,
                     help='Picard iterations per kernel launch (profiles stay in registers in between); 0 = the configuration\'s default')
     ap.add_argument('--check-every', type=int, default=64, help='steps between convergence all-reduces')
+    ap.add_argument('--clock-warmup-ms', type=float, default=50.0,
+                    help='untimed launches before the warm-up steps, until the GPU has been busy this long (0: none)')
     ap.add_argument('--profiles-per-gpu', type=int, default=0)
     ap.add_argument('--n', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -242,6 +244,26 @@ def main():
     run(args.warmup)
     mon.issue()                  # whatever the warm-up length: both collectives have run once before the timed region
     mon.previous()
+    # A GPU that has just been idle, or busy for a millisecond only, runs its next few milliseconds at a lower clock: the
+    # same 20-iteration launch (22 403 vector instructions per wavefront either way, counted with rocprofv3) takes 4.0 ms
+    # after 5 warm-up steps, 3.5 ms after 128 and 3.25 ms after 256 or more.  The requested warm-up can be that short
+    # (5 steps = 1 ms), so the clock is brought up by further untimed launches right before the timed region; they are
+    # neither warm-up steps nor timed steps, are reported as clock_warmup_iterations, and leave the iteration counters
+    # (the columns of the residual history) where the warm-up steps left them.
+    clock_warmup = 0
+    if args.clock_warmup_ms > 0:
+        saved = torch.empty(E.iters.nbytes, dtype=torch.uint8, device=dev)
+        H.check(H.lib.tg_copy_d2d(saved.data_ptr(), E.iters.ptr, E.iters.nbytes, stream.cuda_stream))
+        t_up = time.perf_counter()
+        while (time.perf_counter() - t_up) * 1e3 < args.clock_warmup_ms:
+            for _ in range(4):
+                E.step(stream.cuda_stream, iters=kper)
+                clock_warmup += kper
+            torch.cuda.synchronize()
+        for _ in range(2):
+            E.step(stream.cuda_stream, iters=kper)
+            clock_warmup += kper
+        H.check(H.lib.tg_copy_d2d(E.iters.ptr, saved.data_ptr(), E.iters.nbytes, stream.cuda_stream))
     fence()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     issued_before = mon.issued
@@ -349,6 +371,7 @@ def main():
                        'name': args.config, 'profiles_total': nb_total, 'grid_points': n,
                        'launch_shape': {'iterations_per_launch': kper, 'launches_in_timed_region': launches,
                                         'iterations_in_last_launch': args.steps - (launches - 1) * kper,
+                                        'clock_warmup_iterations': clock_warmup,
                                         'check_every': check, 'all_reduce_rounds_in_timed_region': timed_checks,
                                         'reduced_results_consumed': mon.consumed},
                        'parallelism': f'batch sharded over {world} GPU(s); RCCL all-reduce of 4 int64 counters + 5 fp64 residual '
