@@ -252,6 +252,8 @@ def main():
     # (the columns of the residual history) where the warm-up steps left them.
     clock_warmup = 0
     if args.clock_warmup_ms > 0:
+        if world > 1:
+            dist.barrier(device_ids=[local])     # start together, so that the ranks also reach the timed region's barrier together
         saved = torch.empty(E.iters.nbytes, dtype=torch.uint8, device=dev)
         H.check(H.lib.tg_copy_d2d(saved.data_ptr(), E.iters.ptr, E.iters.nbytes, stream.cuda_stream))
         t_up = time.perf_counter()
