@@ -17,11 +17,11 @@
 namespace tg {
 
 // x / d, either as the division itself (EXACT) or as x * (1/d) with the reciprocal formed once
-// (The EXACT quotient is quot<true> of tg_comm.h: the arithmetic of the IEEE division sequence, bit for bit, for
-// operands in the normal range, at two thirds of its issue slots.)
+// (The EXACT quotient is quot_by of tg_comm.h: the correctly rounded quotient for operands in the normal range from the
+// reciprocal that is at hand anyway, at a quarter of the division's issue slots.)
 template <bool EXACT>
 __device__ __forceinline__ double cdiv(double x, double d, double inv) {
-    if constexpr (EXACT) return quot<kDivRounded>(x, d);
+    if constexpr (EXACT) return quot_by(x, d, inv);
     else return x * inv;
 }
 
@@ -35,20 +35,23 @@ struct Recip {
 };
 
 struct Theta {
-    double Dmin, Dmax, thr, span;
+    double Dmin, Dmax, thr, span, ispan;
     __host__ __device__ Theta(double Dmin_, double Dmax_, double thr_)
-        : Dmin(Dmin_), Dmax(Dmax_), thr(thr_), span(Dmax_ - Dmin_) {}
+        : Dmin(Dmin_), Dmax(Dmax_), thr(thr_), span(Dmax_ - Dmin_), ispan(1.0 / (Dmax_ - Dmin_)) {}
 };
 
 // The default theta rule of tango/lodestro_method.py:667-676.  NaN compares false everywhere, which leaves theta = 1 exactly as the reference's masks do.
 // c = (1-theta)*cHat cancels to ~1e-14 of theta's rounding, so theta must round exactly as the reference's division
-// does.  quot<true> qualifies: it is the arithmetic of the compiler's own IEEE division sequence (reciprocal
-// estimate, two Newton steps, quotient, residual correction) without that sequence's operand scaling and special-case
-// fix-up, which are no-ops for Dmax - DHat and Dmax - Dmin.
+// does.  quot_by qualifies: with the correctly rounded 1/(Dmax - Dmin), formed once by a true division, the product and
+// one residual correction are the last two steps of the IEEE division sequence and give the correctly rounded quotient
+// (that sequence's operand scaling and special-case fix-up are no-ops for Dmax - DHat and Dmax - Dmin).
 template <int FAST = 0>
 __device__ __forceinline__ double theta_point(double dh, double dpdx, const Theta &th) {
     const bool small = fabs(dpdx) < th.thr;
-    const double mid = (1.0 + quot<FAST>(th.Dmax - dh, th.span)) / 2.0;
+    double qm;
+    if constexpr (FAST == kDivIeee) qm = (th.Dmax - dh) / th.span;
+    else qm = quot_by(th.Dmax - dh, th.span, th.ispan);
+    const double mid = (1.0 + qm) / 2.0;
     double tv = 1.0;
     tv = (dh < th.Dmin) ? 0.0 : tv;
     tv = (small && dh >= th.Dmin && dh <= th.Dmax) ? mid : tv;
@@ -112,7 +115,7 @@ template <bool EXACT>
 __device__ __forceinline__ double ddx_edge1_point(double um, double u0, double up, bool first, bool last,
                                                   const Recip &rc) {
     const double num = first ? (up - u0) : (last ? (u0 - um) : (up - um));
-    if constexpr (EXACT) return quot<true>(num, (first || last) ? rc.dx : rc.twodx);
+    if constexpr (EXACT) return quot_by(num, (first || last) ? rc.dx : rc.twodx, (first || last) ? rc.idx : rc.i2dx);
     else return num * ((first || last) ? rc.idx : rc.i2dx);
 }
 
