@@ -358,6 +358,32 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) UL[s] = Q.UL[s][b];
 
+    // Upwinding weights (tango/HToMatrixFD.py:277-297).  Where diffusion dominates, H2 >= |H3| dx / 2 with H3 != 0, the
+    // weight is 1/2 whatever the quotient H2 / (c dx) (the test is exact: halving is, and the rounded quotient is monotone
+    // in its operands).  When that holds at every face of the three fields that this wavefront uses, the quotients are
+    // skipped (a branch the whole wavefront takes or not); weights and rows are the same numbers either way.  The face left
+    // of the first grid point carries H2 = H3 = 0 and its weight multiplies zeros; rows past the end of a ragged grid and
+    // the Dirichlet row do not use theirs.
+    bool half = true;
+    {
+        auto dominated = [&](double h2, double h3) { return (h3 != 0.0) && (h2 >= 0.5 * fabs(h3 * rc.dx)); };
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (!lane_first && (FULL || j0 < n - 1)) half = half && dominated((h2l[s] + DE[s][0]) / 2.0, (h3l[s] + -cE[s][0]) / 2.0);
+            double a2 = DE[s][0], a3 = -cE[s][0];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const bool used = FULL ? !(i == P - 1 && t == G::T - 1) : (j0 + i < n - 1);
+                const double n2 = (i == P - 1) ? h2r[s] : DE[s][i < P - 1 ? i + 1 : 0];
+                const double n3 = (i == P - 1) ? h3r[s] : -cE[s][i < P - 1 ? i + 1 : 0];
+                half = half && (!used || dominated((a2 + n2) / 2.0, (a3 + n3) / 2.0));
+                a2 = n2;
+                a3 = n3;
+            }
+        }
+    }
+    const bool weigh = !__all(half);
+
     double xn[P];
     Vec<2> xp[P];
     double rms = 0.0;
@@ -375,7 +401,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         h3c[s] = -cE[s][0];
         hm2[s] = lane_first ? 0.0 : (h2l[s] + h2c[s]) / 2.0;
         hm3[s] = lane_first ? 0.0 : (h3l[s] + h3c[s]) / 2.0;
-        bm[s] = fbeta_point<DIV>(hm2[s], hm3[s], rc.dx);
+        bm[s] = 0.5;
+        if (weigh) bm[s] = fbeta_point<DIV>(hm2[s], hm3[s], rc.dx);
     }
     double mx[3] = {0.0, 0.0, 0.0}, ss[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -394,7 +421,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             const double h3n = (i == P - 1) ? h3r[s] : -cE[s][i < P - 1 ? i + 1 : 0];
             const double hp2 = (h2c[s] + h2n) / 2.0;
             const double hp3 = (h3c[s] + h3n) / 2.0;
-            const double bp = fbeta_point<DIV>(hp2, hp3, rc.dx);
+            double bp = 0.5;
+            if (weigh) bp = fbeta_point<DIV>(hp2, hp3, rc.dx);
             const double h6 = (s == 0) ? 0.0 : -nu;       // H6 = -nu for pi and pe (example :125, :144)
             fd_row<EXACT>(last, 1.0, TREAD ? u[s][i + 1] : um1[s][TREAD ? 0 : i], rc, UL[s], hm2[s], hm3[s], bm[s], hp2, hp3, bp, 0.0, h6, Q.H7[s][jc], A[s], B[s],
                          C[s], f[s]);

@@ -108,11 +108,14 @@ struct FaceCarry {
     double hm2, hm3, bm, h2c, h3c;
 };
 
+// `weigh` = false: the caller has found diffusion dominant at every face it uses (faces_all_half), the upwinding weight
+// is 1/2 there whatever the quotient and the quotient is skipped; the numbers are the same either way.
 __device__ __forceinline__ void seg_row(FaceCarry &c, double h2n, double h3n, bool last, double H1, double um1, const Recip &rc, double UL,
-                                        double h7, double &A, double &B, double &C, double &f) {
+                                        double h7, bool weigh, double &A, double &B, double &C, double &f) {
     const double hp2 = (c.h2c + h2n) / 2.0;
     const double hp3 = (c.h3c + h3n) / 2.0;
-    const double bp = fbeta_point<kDivRounded>(hp2, hp3, rc.dx);
+    double bp = 0.5;
+    if (weigh) bp = fbeta_point<kDivRounded>(hp2, hp3, rc.dx);
     fd_row<true>(last, H1, um1, rc, UL, c.hm2, c.hm3, c.bm, hp2, hp3, bp, 0.0, 0.0, h7, A, B, C, f);
     c.hm2 = hp2;
     c.hm3 = hp3;
@@ -185,7 +188,7 @@ __device__ __forceinline__ void boundary_next_profile(const tg_state_1f &S_, con
         const double H1 = Q.H1 ? Q.H1[j] : 1.0;
         const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + j] : ((j < src_cut) ? S0 : 0.0);
         double A, B, C, f;
-        seg_row(c, DEp[j + 1], -cEp[j + 1], false, H1, mp[j], rc, UL, h7, A, B, C, f);
+        seg_row(c, DEp[j + 1], -cEp[j + 1], false, H1, mp[j], rc, UL, h7, true, A, B, C, f);
         el.push(i, C, B, A, f);
     }
     const double y = y_of_lane[lane_r];
@@ -296,10 +299,32 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
             u[0] = edge_l ? h_u : ul;
             u[P + 1] = edge_r ? h_u : ur;
         }
+        // Upwinding weights (tango/HToMatrixFD.py:277-297).  Where diffusion dominates, H2 >= |H3| dx / 2 with H3 != 0, the
+        // weight is 1/2 whatever the quotient H2 / (c dx) (the test is exact: halving is, and the rounded quotient is monotone
+        // in its operands).  When that holds at every face this wavefront uses, the quotients are skipped (a branch the whole
+        // wavefront takes or not); weights and rows are the same numbers either way.  The face left of the profile's first
+        // point carries H2 = H3 = 0 and its weight multiplies zeros; the Dirichlet row does not use its right face.
+        bool half = true;
+        {
+            auto dominated = [&](double h2, double h3) { return (h3 != 0.0) && (h2 >= 0.5 * fabs(h3 * rc.dx)); };
+            if (!first_lane) half = dominated((h2l + DE[0]) / 2.0, (h3l - cE[0]) / 2.0);
+            double a2 = DE[0], a3 = -cE[0];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const bool used = !((i == P - 1) && last_lane);
+                const double n2 = (i == P - 1) ? h2r : DE[i < P - 1 ? i + 1 : 0];
+                const double n3 = (i == P - 1) ? h3r : -cE[i < P - 1 ? i + 1 : 0];
+                half = half && (!used || dominated((a2 + n2) / 2.0, (a3 + n3) / 2.0));
+                a2 = n2;
+                a3 = n3;
+            }
+        }
+        const bool weigh = !__all(half);
         FaceCarry c;
         c.hm2 = first_lane ? 0.0 : (h2l + DE[0]) / 2.0;
         c.hm3 = first_lane ? 0.0 : (h3l - cE[0]) / 2.0;
-        c.bm = fbeta_point<kDivRounded>(c.hm2, c.hm3, rc.dx);
+        c.bm = 0.5;
+        if (weigh) c.bm = fbeta_point<kDivRounded>(c.hm2, c.hm3, rc.dx);
         c.h2c = DE[0];
         c.h3c = -cE[0];
 #pragma unroll
@@ -311,7 +336,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
             const double H1 = Q.H1 ? Q.H1[j] : 1.0;
             const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + j] : ((j < src_cut) ? S0 : 0.0);
             double A, B, C, f;
-            seg_row(c, h2n, h3n, last, H1, um1[i], rc, UL, h7, A, B, C, f);
+            seg_row(c, h2n, h3n, last, H1, um1[i], rc, UL, h7, weigh, A, B, C, f);
             if constexpr (RESID) {
                 const double r = A * u[i + 2] + B * u[i + 1] + C * u[i] - f;
                 ss += r * r;
