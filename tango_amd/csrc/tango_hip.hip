@@ -1058,7 +1058,6 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 const int j = j0 + i;
-                const int jc = (FULL || j < n) ? j : n - 1;
                 const bool first = (i == 0) && lane_first;
                 const bool last = FULL ? (i == P - 1 && t == G::T - 1) : (j == n - 1);
                 const double pm = (i == 0) ? wl : ue[i > 0 ? i - 1 : 0];
@@ -1145,6 +1144,26 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                 }
             }
         }
+        // H1 and H7 of this lane's rows.  Arrays for them exist only in the GENERAL form (the launcher sends such calls
+        // there); their loads are issued, and waited for, before the first store of the launch: a wait for a load that
+        // follows stores also waits for those stores to reach memory.
+        double H1v[GENERAL ? P : 1], h7v[GENERAL ? P : 1];
+        if constexpr (GENERAL) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int j = j0 + i;
+                const int jc = (FULL || j < n) ? j : n - 1;
+                H1v[i] = Q.H1 ? Q.H1[jc] : 1.0;
+                h7v[i] = Q.H7 ? Q.H7[b * Q.h7_stride + jc] : ((j < src_cut) ? S0 : 0.0);
+            }
+            if constexpr (EARLY) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    landed(H1v[i]);
+                    landed(h7v[i]);
+                }
+            }
+        }
         if constexpr (EARLY) {
             if (!Q.frozen_turb) store_state(false, true);
         }
@@ -1210,15 +1229,17 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             const int j = j0 + i;
             const bool valid = FULL || (j < n);
             const bool last = FULL ? (i == P - 1 && t == G::T - 1) : (j == n - 1);
-            const int jc = valid ? j : n - 1;
             const double h2n = (i == P - 1) ? h2r : H2at(i < P - 1 ? i + 1 : 0);
             const double h3n = (i == P - 1) ? h3r : H3at(i < P - 1 ? i + 1 : 0);
             const double hp2 = (h2c + h2n) / 2.0;
             const double hp3 = (h3c + h3n) / 2.0;
             double bp = 0.5;
             if (!half_everywhere) bp = fbeta_point<DIV>(hp2, hp3, rc.dx);
-            const double H1 = Q.H1 ? Q.H1[jc] : 1.0;
-            const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + jc] : ((j < src_cut) ? S0 : 0.0);
+            double H1 = 1.0, h7 = (j < src_cut) ? S0 : 0.0;
+            if constexpr (GENERAL) {
+                H1 = H1v[i];
+                h7 = h7v[i];
+            }
             double A, B, C, f;
             fd_row<EXACT>(last, H1, um1[i], rc, UL, hm2, hm3, bm, hp2, hp3, bp, 0.0, 0.0, h7, A, B, C, f);
             if (!FULL) {
@@ -1365,7 +1386,7 @@ struct Picard1fLauncher {
                        reinterpret_cast<uintptr_t>(q->gradx_turb) | reinterpret_cast<uintptr_t>(q->iterates);
         const bool full = (n == P * G::T) && (al & 15) == 0;
         const bool general = q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly ||
-                             q->smooth_window > 1 || q->flux_mult;
+                             q->smooth_window > 1 || q->flux_mult || q->H1 || q->H7;
         const bool multi = q->iters_per_launch > 1;
         if (kWaveCoop<P, G, true> && full) lds += (size_t)(block / 64) * kCoopTiles<G> * WaveTile<8>::kDoubles * sizeof(double);
         tg_params_1f qs = *q;

@@ -84,6 +84,11 @@ __device__ __forceinline__ double swap_halves(double v, bool upper) {
     return __hiloint2double((int)(upper ? b[0] : b[1]), (int)(upper ? a[0] : a[1]));
 }
 
+// Marks the point by which a loaded value must have arrived: the compiler places the wait for its load here and none
+// later.  Used ahead of a kernel's first store, because a wait for a load also waits for every store issued before it
+// (loads and stores share one counter and leave it in order).
+__device__ __forceinline__ void landed(double &x) { asm volatile("" : "+v"(x)); }
+
 // Index of this wavefront within its workgroup.  It is the same in every lane; read through the first lane so that the
 // compiler knows, and keeps what is derived from it (row offsets, tile addresses, per-profile parameters) in scalar registers.
 __device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
