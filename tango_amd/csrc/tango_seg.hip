@@ -219,8 +219,11 @@ __device__ __forceinline__ void boundary_next_profile(const tg_state_1f &S_, con
 //          that an edge lane needs from the neighbouring segment come from the reduce kernel (boundary_next_profile).
 // wavefronts per SIMD: three (<= 168 registers) and four (<= 128) for the two halves; the combined kernel needs 216
 // registers, and with them at two per SIMD it measured 17 % faster than with 168 and 48 of them spilled
-template <int PHASE>
-__global__ void __launch_bounds__(256, PHASE == 0 ? 3 : (PHASE == 1 ? 4 : 2))
+// ARR: H1 or H7 come as arrays (otherwise H1 = 1 and H7 is the box source of the profile: no loads).
+// No load follows a store in these kernels (a wait for such a load would also wait for the stores before it to reach
+// memory): whatever the later parts need from memory is fetched at the top.
+template <int PHASE, bool ARR>
+__global__ void __launch_bounds__(256, PHASE == 0 ? (ARR ? 2 : 3) : (PHASE == 1 ? (ARR ? 3 : 4) : 2))
 picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
     extern __shared__ double lds[];
     using G = WaveGroup<64>;
@@ -265,6 +268,14 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
     Tile wt(lds + wave * NT * Tile::kDoubles);
 
     double u[P + 2], um1[P], DE[P], cE[P];
+    double H1v[ARR ? P : 1], h7v[ARR ? P : 1];
+    if constexpr (ARR) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            H1v[i] = Q.H1 ? Q.H1[j0 + i] : 1.0;
+            h7v[i] = Q.H7 ? Q.H7[b * Q.h7_stride + j0 + i] : ((j0 + i < src_cut) ? S0 : 0.0);
+        }
+    }
     // values at the point just outside this wavefront's segment, on the side of this lane if it is lane 0 or 63
     // (nothing there for the two ends of the profile): new EWMA profile, H2, H3, current profile
     const bool edge_l = (t == 0 && s > 0), edge_r = (t == 63 && s < S - 1);
@@ -333,8 +344,11 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
             const bool last = (i == P - 1) && last_lane;
             const double h2n = (i == P - 1) ? h2r : DE[i < P - 1 ? i + 1 : 0];
             const double h3n = (i == P - 1) ? h3r : -cE[i < P - 1 ? i + 1 : 0];
-            const double H1 = Q.H1 ? Q.H1[j] : 1.0;
-            const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + j] : ((j < src_cut) ? S0 : 0.0);
+            double H1 = 1.0, h7 = (j < src_cut) ? S0 : 0.0;
+            if constexpr (ARR) {
+                H1 = H1v[i];
+                h7 = h7v[i];
+            }
             double A, B, C, f;
             seg_row(c, h2n, h3n, last, H1, um1[i], rc, UL, h7, weigh, A, B, C, f);
             if constexpr (RESID) {
@@ -353,12 +367,24 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         wt.fetch(S_.cE + woff, r3);
         wt.fetch(S_.um1 + woff, r4);
         if (PHASE == 2) wt.fetch(S_.uE + woff, r1);
+        // this lane's last unknown and its left neighbour's (any segment), for the back substitution
+        const double y = W.y[lane_id];
+        const double yl = first_lane ? 0.0 : W.y[lane_slot(b, n, lane_r - 1)];
+        int sing0 = 0, it_old = 0;
+        if (s == 0) {
+            sing0 = W.sing[b];
+            it_old = S_.iters[b];
+        }
         if (edge_l || edge_r) {
             if (PHASE == 2) {
                 // the neighbours may already be replacing their memories: the copies taken before this launch
                 snapshot();
                 h_D = n_D;
                 h_c = n_c;
+                // the neighbouring segment's new profile next to the boundary, for the first half that follows
+                const double *h = W.halo + kHaloQ * (b * (S - 1) + (edge_l ? s - 1 : s));
+                n_u0 = edge_l ? h[9] : h[10];
+                n_u1 = edge_l ? h[8] : h[11];
             } else {
                 h_D = S_.DE[off + jh];
                 h_c = S_.cE[off + jh];
@@ -379,9 +405,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         ChunkElim<P, kDivRounded> el;
         double mx = 0.0, ss = 0.0;
         assemble(std::false_type{}, el, ss, mx);
-        // back substitution with this lane's last unknown y and its left neighbour's (any segment)
-        const double y = W.y[lane_id];
-        const double yl = first_lane ? 0.0 : W.y[lane_slot(b, n, lane_r - 1)];
+        // back substitution
         double x[P];
         x[P - 1] = y;
 #pragma unroll
@@ -398,11 +422,11 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
             int bits = (bad && mode == kPlain) ? TG_ST_INVALID : 0;
             if (s == 0) {
                 if (mode != kRetry) {
-                    S_.iters[b] += 1;
+                    S_.iters[b] = it_old + 1;
                     if (turb) bits |= TG_ST_SEEDED;
                     if (flag == 2) bits |= TG_ST_CONVERGED;
                 }
-                if (W.sing[b]) bits |= TG_ST_SINGULAR;
+                if (sing0) bits |= TG_ST_SINGULAR;
             }
             if (bits) atomicOr(&S_.status[b], bits);
         }
@@ -413,12 +437,6 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         Tile::sync();
 #pragma unroll
         for (int i = 0; i < P; ++i) u[i + 1] = x[i];
-        // the neighbouring segment's new profile next to the boundary
-        if (edge_l || edge_r) {
-            const double *h = W.halo + kHaloQ * (b * (S - 1) + (edge_l ? s - 1 : s));
-            n_u0 = edge_l ? h[9] : h[10];
-            n_u1 = edge_l ? h[8] : h[11];
-        }
     }
 
     // ---- first half of an iteration ----
@@ -672,6 +690,12 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next, in
     }
 }
 
+template <int PHASE>
+void seg_launch(bool arr, unsigned grid, size_t lds, hipStream_t s, const tg_state_1f &st, const tg_params_1f &q, const SegWork &W, int mode) {
+    if (arr) hipLaunchKernelGGL((picard_seg_kernel<PHASE, true>), dim3(grid), dim3(256), lds, s, st, q, W, mode);
+    else hipLaunchKernelGGL((picard_seg_kernel<PHASE, false>), dim3(grid), dim3(256), lds, s, st, q, W, mode);
+}
+
 }  // namespace
 
 // entry points for tango_hip.hip (C++ linkage: not part of the C ABI)
@@ -724,6 +748,7 @@ int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
     };
     const dim3 hgrid((unsigned)((bounds + 255) / 256));
     const int iters = q->iters_per_launch > 1 ? q->iters_per_launch : 1;
+    const bool arr = q->H1 || q->H7;
     if (q->pseudo_time) {
         // Pseudo-timestep control: one iteration at a time.  The previous iterate and the profiles' pseudo-timesteps go
         // into the work space; with tread_lightly every attempt is followed by a check, and while the
@@ -739,9 +764,9 @@ int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
             hipLaunchKernelGGL(seg_tread_init_kernel, dim3(pgrid), dim3(256), 0, s, *st, *q, W);
             TG_HIP(hipMemcpyAsync(W.uprev, st->u, sizeof(double) * (size_t)nb * (size_t)n, hipMemcpyDeviceToDevice, s));
             hipLaunchKernelGGL(seg_halo_kernel, hgrid, dim3(256), 0, s, sp, W);
-            hipLaunchKernelGGL((picard_seg_kernel<0>), dim3(grid), dim3(256), lds0, s, sp, p, W, first);
+            seg_launch<0>(arr, grid, lds0, s, sp, p, W, first);
             reduce(sp, p, 0, first);
-            hipLaunchKernelGGL((picard_seg_kernel<1>), dim3(grid), dim3(256), lds1, s, sp, p, W, first);
+            seg_launch<1>(arr, grid, lds1, s, sp, p, W, first);
             if (!q->tread_lightly) continue;
             tg_params_1f r = p;
             r.frozen_turb = 1;          // further attempts keep D and c (tango/solver.py:361-371)
@@ -754,22 +779,22 @@ int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
                 if (attempt > TG_TREAD_MAX_HALVINGS) return fail(TG_ERR_HIP, "segmented form: the halving loop did not end%s");
                 TG_HIP(hipMemsetAsync(W.nredo, 0, sizeof(int32_t), s));
                 hipLaunchKernelGGL(seg_halo_kernel, hgrid, dim3(256), 0, s, sp, W);      // the memories as they are now
-                hipLaunchKernelGGL((picard_seg_kernel<0>), dim3(grid), dim3(256), lds0, s, sp, r, W, kRetry);
+                seg_launch<0>(arr, grid, lds0, s, sp, r, W, kRetry);
                 reduce(sp, r, 0, kRetry);
-                hipLaunchKernelGGL((picard_seg_kernel<1>), dim3(grid), dim3(256), lds1, s, sp, r, W, kRetry);
+                seg_launch<1>(arr, grid, lds1, s, sp, r, W, kRetry);
             }
         }
         return launch_check();
     }
     // iterations of one call: first half, reduce, then (second half + next first half), reduce, ... and the last second half
     hipLaunchKernelGGL(seg_halo_kernel, hgrid, dim3(256), 0, s, *st, W);
-    hipLaunchKernelGGL((picard_seg_kernel<0>), dim3(grid), dim3(256), lds0, s, *st, *q, W, kPlain);
+    seg_launch<0>(arr, grid, lds0, s, *st, *q, W, kPlain);
     for (int k = 1; k < iters; ++k) {
         reduce(*st, *q, 1, kPlain);
-        hipLaunchKernelGGL((picard_seg_kernel<2>), dim3(grid), dim3(256), lds0, s, *st, *q, W, kPlain);
+        seg_launch<2>(arr, grid, lds0, s, *st, *q, W, kPlain);
     }
     reduce(*st, *q, 0, kPlain);
-    hipLaunchKernelGGL((picard_seg_kernel<1>), dim3(grid), dim3(256), lds1, s, *st, *q, W, kPlain);
+    seg_launch<1>(arr, grid, lds1, s, *st, *q, W, kPlain);
     return launch_check();
 }
 
