@@ -223,7 +223,7 @@ __device__ __forceinline__ void boundary_next_profile(const tg_state_1f &S_, con
 // No load follows a store in these kernels (a wait for such a load would also wait for the stores before it to reach
 // memory): whatever the later parts need from memory is fetched at the top.
 template <int PHASE, bool ARR>
-__global__ void __launch_bounds__(256, PHASE == 0 ? (ARR ? 2 : 3) : (PHASE == 1 ? (ARR ? 3 : 4) : 2))
+__global__ void __launch_bounds__(256, PHASE == 0 ? (ARR ? 2 : 3) : (PHASE == 1 ? (ARR ? 3 : 4) : (ARR ? 2 : 3)))
 picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
     extern __shared__ double lds[];
     using G = WaveGroup<64>;
@@ -250,7 +250,10 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
     const int64_t off = b * S_.n;
     const int64_t woff = off + (int64_t)s * kSeg;
     const int lane_r = s * 64 + t;                                    // this lane within its profile
-    const int64_t lane_id = lane_slot(b, n, lane_r);                  // its slot in the per-lane work arrays
+    // its slot in the per-lane work arrays (lane_slot): the profile's part is the same for the whole wavefront and stays
+    // in scalar registers, the lane's own part is a 32-bit offset
+    const int64_t lane_base = b * (n / 8);
+    const int lane_off = (lane_r & 7) * (n / 64) + (lane_r >> 3);
     const bool first_lane = (s == 0 && t == 0);      // holds the first point of the profile
     const bool last_lane = (s == S - 1 && t == 63);  // holds the last point of the profile (Dirichlet row)
     const Recip rc(Q.dx, Q.dt_b ? Q.dt_b[b] : Q.dt);
@@ -368,12 +371,12 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         wt.fetch(S_.um1 + woff, r4);
         if (PHASE == 2) wt.fetch(S_.uE + woff, r1);
         // this lane's last unknown and its left neighbour's (any segment), for the back substitution
-        const double y = W.y[lane_id];
-        const double yl = first_lane ? 0.0 : W.y[lane_slot(b, n, lane_r - 1)];
+        const double y = (W.y + lane_base)[lane_off];
+        const double yl = first_lane ? 0.0 : (W.y + lane_base)[((lane_r - 1) & 7) * (n / 64) + ((lane_r - 1) >> 3)];
         int sing0 = 0, it_old = 0;
         if (s == 0) {
-            sing0 = W.sing[b];
-            it_old = S_.iters[b];
+            sing0 = __builtin_amdgcn_readfirstlane(W.sing[b]);
+            it_old = __builtin_amdgcn_readfirstlane(S_.iters[b]);
         }
         if (edge_l || edge_r) {
             if (PHASE == 2) {
@@ -401,6 +404,18 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         Tile::sync();
         wt.take(0, um1);
         Tile::sync();
+        // What only the two edge lanes will need in the first half that follows waits in LDS meanwhile (six values per
+        // edge lane, in registers they would be six doubles of every lane held through the whole second half): 179 -> 168
+        // registers, three wavefronts per SIMD.
+        double *park = lds + 4 * NT * Tile::kDoubles + wave * 16 + (edge_r ? 8 : 0);
+        if (PHASE == 2 && (edge_l || edge_r)) {
+            park[0] = n_u0;
+            park[1] = n_u1;
+            park[2] = n_e0;
+            park[3] = n_e1;
+            park[4] = n_D;
+            park[5] = n_c;
+        }
 
         ChunkElim<P, kDivRounded> el;
         double mx = 0.0, ss = 0.0;
@@ -437,6 +452,15 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         Tile::sync();
 #pragma unroll
         for (int i = 0; i < P; ++i) u[i + 1] = x[i];
+        asm volatile("" ::: "memory");      // the parked values are to be read back from LDS, not kept in registers
+        if (edge_l || edge_r) {
+            n_u0 = park[0];
+            n_u1 = park[1];
+            n_e0 = park[2];
+            n_e1 = park[3];
+            n_D = park[4];
+            n_c = park[5];
+        }
     }
 
     // ---- first half of an iteration ----
@@ -512,9 +536,13 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
             wt.put(1, DE);
             wt.put(2, cE);
             Tile::sync();
-            wt.flush(0, S_.uE + woff);
-            wt.flush(1, S_.DE + woff);
-            wt.flush(2, S_.cE + woff);
+            // (the offset taken through an empty asm: the store addresses are then formed here, not at the top of the kernel
+            // to be carried, or spilled, all the way)
+            int64_t wo = woff;
+            asm volatile("" : "+s"(wo));
+            wt.flush(0, S_.uE + wo);
+            wt.flush(1, S_.DE + wo);
+            wt.flush(2, S_.cE + wo);
         } else {
             h_D = n_D;
             h_c = n_c;
@@ -542,10 +570,10 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         const double F0 = g.from_right(F, 1, 0.0), E0 = g.from_right(E, 1, 0.0), T0 = g.from_right(tau, 1, 1.0);
         const double e7 = el.e[P - 1], l7 = el.l[P - 1], f7 = el.f[P - 1], r7 = el.rho[P - 1];
         const bool own = (t == 63);
-        W.row[0][lane_id] = own ? e7 : l7;
-        W.row[1][lane_id] = own ? l7 : -(e7 * E0);
-        W.row[2][lane_id] = own ? f7 : f7 - e7 * F0;
-        W.row[3][lane_id] = own ? r7 : r7 - e7 * T0;
+        (W.row[0] + lane_base)[lane_off] = own ? e7 : l7;
+        (W.row[1] + lane_base)[lane_off] = own ? l7 : -(e7 * E0);
+        (W.row[2] + lane_base)[lane_off] = own ? f7 : f7 - e7 * F0;
+        (W.row[3] + lane_base)[lane_off] = own ? r7 : r7 - e7 * T0;
         mx = g.max(mx);
         ss = g.sum(ss);
         const int sing = g.any(el.singular);
@@ -731,7 +759,7 @@ int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
     const int64_t segs = nb * (n / kSeg);
     const unsigned grid = (unsigned)((segs + 3) / 4);
     const size_t tile = 4 * WaveTile<8>::kDoubles * sizeof(double);     // one tile for each of the four wavefronts
-    const size_t lds0 = 3 * tile, lds1 = 2 * tile;
+    const size_t lds0 = 3 * tile + 4 * 16 * sizeof(double), lds1 = 2 * tile;      // + the edge lanes' parking places of the combined kernel
     const int64_t bounds = nb * (n / kSeg - 1);
     const int lanes = n / 64;      // threads of the reduce kernel: 8 reduced rows each
     const size_t lds_r = sizeof(double) * 8 * (size_t)lanes;
