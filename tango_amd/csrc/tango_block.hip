@@ -177,6 +177,17 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     const int64_t woff = off + (G::kBlock ? (int64_t)wave_in_block() * 64 * P : 0);   // this wavefront's segment
     const bool turb = !Q.frozen_turb;
 
+    // Per-profile scalars and the sources of this lane's rows, fetched before anything is stored: a wait for a load also
+    // waits for every store issued before it (see `landed`), and the first stores come early in this kernel.
+    const double nu0 = Q.nu0[b];
+    double UL[3], h7v[3][P];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        UL[s] = Q.UL[s][b];
+#pragma unroll
+        for (int i = 0; i < P; ++i) h7v[s][i] = Q.H7[s][(FULL || j0 + i < n) ? j0 + i : n - 1];
+    }
+
     double u[3][P + 2], DE[3][P], cE[3][P];
     double2 rE[3][KP], rm[3][KP];      // coalesced path: raw uE and u_{m-1} pieces, staged when they are needed
     if constexpr (COOP) {
@@ -227,6 +238,25 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             return a * y + om * (seeded ? mem : y);
         }
     };
+    // u_{m-1} from its raw pieces, through tiles 0..2 (free when this is called, and again afterwards): done before the
+    // first store of the launch on either path below, like the waits for the other late loads (all_landed)
+    double um1[3][TREAD ? 1 : P];
+    auto stage_um1 = [&]() {
+        if constexpr (COOP && !TREAD) {
+            wt.stage(0, rm[0]); wt.stage(1, rm[1]); wt.stage(2, rm[2]);
+            Tile::sync();
+            wt.take(0, um1[0]); wt.take(1, um1[1]); wt.take(2, um1[2]);
+            Tile::sync();
+        }
+    };
+    auto all_landed = [&]() {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            landed(UL[s]);
+#pragma unroll
+            for (int i = 0; i < P; ++i) landed(h7v[s][i]);
+        }
+    };
     if (turb) {
         double ue[3][P + 2];
 #pragma unroll
@@ -239,8 +269,10 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         }
         if constexpr (COOP) {
             Tile::sync();
+            stage_um1();
             wt.put(1, ue[0] + 1); wt.put(2, ue[1] + 1); wt.put(3, ue[2] + 1);
             Tile::sync();
+            all_landed();      // ahead of the first store
             wt.flush(1, S_.uE[0] + woff); wt.flush(2, S_.uE[1] + woff); wt.flush(3, S_.uE[2] + woff);
             Tile::sync();
         }
@@ -308,6 +340,10 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
                 store_chunk<P, false>(S_.cE[s] + off, n, j0, cE[s]);
             }
         }
+    } else {
+        if constexpr (COOP) Tile::sync();
+        stage_um1();
+        all_landed();
     }
     if constexpr (COOP) Tile::sync();
 
@@ -341,22 +377,14 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         for (int s = 0; s < 3; ++s) u[s][0] = 0.0;
     }
 
-    double um1[3][TREAD ? 1 : P];
     if constexpr (TREAD) {
         // the previous iterate takes the u_{m-1} slot (tango/solver.py:198-201): read from u below
     } else if constexpr (COOP) {
-        wt.stage(0, rm[0]); wt.stage(1, rm[1]); wt.stage(2, rm[2]);
-        Tile::sync();
-        wt.take(0, um1[0]); wt.take(1, um1[1]); wt.take(2, um1[2]);
-        Tile::sync();
+        // staged above
     } else {
 #pragma unroll
         for (int s = 0; s < 3; ++s) load_chunk<P, false>(S_.um1[s] + off, n, j0, um1[s], 0.0);
     }
-    const double nu0 = Q.nu0[b];
-    double UL[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) UL[s] = Q.UL[s][b];
 
     // Upwinding weights (tango/HToMatrixFD.py:277-297).  Where diffusion dominates, H2 >= |H3| dx / 2 with H3 != 0, the
     // weight is 1/2 whatever the quotient H2 / (c dx) (the test is exact: halving is, and the rounded quotient is monotone
@@ -410,7 +438,6 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         const int j = j0 + i;
         const bool valid = FULL || j < n;      // FULL: n = lanes x P, the tests fold away
         const bool last = FULL ? (i == P - 1 && t == G::T - 1) : (j == n - 1);
-        const int jc = valid ? j : n - 1;
         // collisional coupling nu = nu0 / ((pi + pe)/n)^{3/2} from the current profiles (example :108-110)
         const double q = quot<DIV>(u[1][i + 1], u[0][i + 1]) + quot<DIV>(u[2][i + 1], u[0][i + 1]);
         const double nu = quot<DIV>(nu0, q * sqrt(q));
@@ -424,7 +451,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             double bp = 0.5;
             if (weigh) bp = fbeta_point<DIV>(hp2, hp3, rc.dx);
             const double h6 = (s == 0) ? 0.0 : -nu;       // H6 = -nu for pi and pe (example :125, :144)
-            fd_row<EXACT>(last, 1.0, TREAD ? u[s][i + 1] : um1[s][TREAD ? 0 : i], rc, UL[s], hm2[s], hm3[s], bm[s], hp2, hp3, bp, 0.0, h6, Q.H7[s][jc], A[s], B[s],
+            fd_row<EXACT>(last, 1.0, TREAD ? u[s][i + 1] : um1[s][TREAD ? 0 : i], rc, UL[s], hm2[s], hm3[s], bm[s], hp2, hp3, bp, 0.0, h6, h7v[s][i], A[s], B[s],
                          C[s], f[s]);
             if (!valid) {
                 A[s] = 0.0; B[s] = 1.0; C[s] = 0.0; f[s] = 0.0;

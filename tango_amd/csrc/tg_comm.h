@@ -88,6 +88,10 @@ __device__ __forceinline__ double swap_halves(double v, bool upper) {
 // later.  Used ahead of a kernel's first store, because a wait for a load also waits for every store issued before it
 // (loads and stores share one counter and leave it in order).
 __device__ __forceinline__ void landed(double &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void landed(double2 &x) {
+    landed(x.x);
+    landed(x.y);
+}
 
 // Index of this wavefront within its workgroup.  It is the same in every lane; read through the first lane so that the
 // compiler knows, and keeps what is derived from it (row offsets, tile addresses, per-profile parameters) in scalar registers.
@@ -248,10 +252,14 @@ struct BlockGroup {
 #pragma unroll
         for (int q = 0; q < CNT; ++q) lds_[q * T_ + t_] = v[q];
         __syncthreads();
+        // every thread reads (a thread at the end reads the row T_ places away and drops it): selects, not branches
+        const int tl = (t_ - h) & (T_ - 1), tr = (t_ + h) & (T_ - 1);
+        const bool hasl = t_ >= h, hasr = t_ + h < T_;
 #pragma unroll
         for (int q = 0; q < CNT; ++q) {
-            l[q] = (t_ >= h) ? lds_[q * T_ + t_ - h] : 0.0;
-            r[q] = (t_ + h < T_) ? lds_[q * T_ + t_ + h] : 0.0;
+            const double a = lds_[q * T_ + tl], c = lds_[q * T_ + tr];
+            l[q] = hasl ? a : 0.0;
+            r[q] = hasr ? c : 0.0;
         }
         __syncthreads();
     }
@@ -292,7 +300,19 @@ struct BlockGroup {
         __syncthreads();
         return tot;
     }
-    __device__ int any(int pred) const { return __syncthreads_or(pred); }
+    // OR of the two flag bits 0 and 1 of `pred` over the workgroup.  (Not __syncthreads_or: that one reads the
+    // workgroup's size from memory, and a wait for that load also waits for every store the wavefront has issued.)
+    __device__ int any(int pred) const {
+        const int mine = (__ballot(pred & 1) != 0 ? 1 : 0) | (__ballot(pred & 2) != 0 ? 2 : 0);
+        int *flags = reinterpret_cast<int *>(lds_);
+        if ((t_ & 63) == 0) flags[t_ >> 6] = mine;
+        __syncthreads();
+        int all = 0;
+#pragma unroll
+        for (int w = 0; w < T_ / 64; ++w) all |= flags[w];
+        __syncthreads();
+        return all;
+    }
     // CNT maxima and CNT sums over the workgroup with one pair of barriers; needs 2*CNT*(T_/64) doubles of LDS.
     // The per-wavefront partial results are combined in wavefront order, as sum() and max() combine them.
     template <int CNT>
