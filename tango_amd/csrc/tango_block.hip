@@ -238,25 +238,25 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             return a * y + om * (seeded ? mem : y);
         }
     };
-    // u_{m-1} from its raw pieces, through tiles 0..2 (free when this is called, and again afterwards): done before the
-    // first store of the launch on either path below, like the waits for the other late loads (all_landed)
+    // u_{m-1} from its raw pieces, through tile 0 (the others may hold the staged profile memories), and the waits for the
+    // other late loads: here, on the one path every wavefront takes, so that no wait for a load is left for after the
+    // first store
     double um1[3][TREAD ? 1 : P];
-    auto stage_um1 = [&]() {
-        if constexpr (COOP && !TREAD) {
-            wt.stage(0, rm[0]); wt.stage(1, rm[1]); wt.stage(2, rm[2]);
-            Tile::sync();
-            wt.take(0, um1[0]); wt.take(1, um1[1]); wt.take(2, um1[2]);
-            Tile::sync();
-        }
-    };
-    auto all_landed = [&]() {
+    if constexpr (COOP && !TREAD) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            landed(UL[s]);
-#pragma unroll
-            for (int i = 0; i < P; ++i) landed(h7v[s][i]);
+            Tile::sync();
+            wt.stage(0, rm[s]);
+            Tile::sync();
+            wt.take(0, um1[s]);
         }
-    };
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        landed(UL[s]);
+#pragma unroll
+        for (int i = 0; i < P; ++i) landed(h7v[s][i]);
+    }
     if (turb) {
         double ue[3][P + 2];
 #pragma unroll
@@ -269,10 +269,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         }
         if constexpr (COOP) {
             Tile::sync();
-            stage_um1();
             wt.put(1, ue[0] + 1); wt.put(2, ue[1] + 1); wt.put(3, ue[2] + 1);
             Tile::sync();
-            all_landed();      // ahead of the first store
             wt.flush(1, S_.uE[0] + woff); wt.flush(2, S_.uE[1] + woff); wt.flush(3, S_.uE[2] + woff);
             Tile::sync();
         }
@@ -340,10 +338,6 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
                 store_chunk<P, false>(S_.cE[s] + off, n, j0, cE[s]);
             }
         }
-    } else {
-        if constexpr (COOP) Tile::sync();
-        stage_um1();
-        all_landed();
     }
     if constexpr (COOP) Tile::sync();
 
