@@ -133,18 +133,25 @@ __device__ __forceinline__ double back_step(double f, double l, double e, double
 // A first half replaces uE, DE and cE in place while neighbouring segments still need the old values next to their
 // boundaries: those are copied aside first.  Boundary k of profile b lies before point jb = 512 (k + 1).
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void boundary_values(const tg_state_1f &S_, int64_t b, int k, double (&v)[8]) {
+    const int64_t j = b * S_.n + (int64_t)(k + 1) * kSeg;
+    v[0] = S_.uE[j - 2];
+    v[1] = S_.uE[j - 1];
+    v[2] = S_.uE[j];
+    v[3] = S_.uE[j + 1];
+    v[4] = S_.DE[j - 1];
+    v[5] = S_.DE[j];
+    v[6] = S_.cE[j - 1];
+    v[7] = S_.cE[j];
+}
+
 __device__ __forceinline__ void boundary_snapshot(const tg_state_1f &S_, const SegWork &W, int64_t b, int k) {
     const int S = (int)(S_.n / kSeg);
-    const int64_t j = b * S_.n + (int64_t)(k + 1) * kSeg;
+    double v[8];
+    boundary_values(S_, b, k, v);
     double *h = W.halo + kHaloQ * (b * (S - 1) + k);
-    h[0] = S_.uE[j - 2];
-    h[1] = S_.uE[j - 1];
-    h[2] = S_.uE[j];
-    h[3] = S_.uE[j + 1];
-    h[4] = S_.DE[j - 1];
-    h[5] = S_.DE[j];
-    h[6] = S_.cE[j - 1];
-    h[7] = S_.cE[j];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) h[q] = v[q];
 }
 
 __global__ void seg_halo_kernel(tg_state_1f S_, SegWork W) {
@@ -161,21 +168,19 @@ __global__ void seg_halo_kernel(tg_state_1f S_, SegWork W) {
 // (rows 0..6, the same row function and elimination as the segment kernels) and its back substitution from the lane
 // unknowns y (indexed by lane within the profile), exactly as the owner of those rows will.
 // side 0: last lane of the segment on the left, 1: first lane of the segment on the right.
-__device__ __forceinline__ void boundary_next_profile(const tg_state_1f &S_, const tg_params_1f &Q, const SegWork &W, int64_t b, int k,
-                                                      int side, const double *y_of_lane) {
+// The sweep reads only what the first halves left (no lane unknowns yet) and is done before the reduced system is
+// solved, its loads next to the solver's own; boundary_finish then needs y alone.
+__device__ __forceinline__ void boundary_sweep(const tg_state_1f &S_, const tg_params_1f &Q, int64_t b, int k, int side,
+                                               ChunkElim<8, kDivRounded> &el) {
     constexpr int P = 8;
-    const int S = (int)(S_.n / kSeg);
     const int64_t off = b * S_.n;
     const int jb = (k + 1) * kSeg;
-    double *h = W.halo + kHaloQ * (b * (S - 1) + k);
     const int j0 = side ? jb : jb - P;            // the lane's first point
-    const int lane_r = j0 / P;
     const Recip rc(Q.dx, Q.dt_b ? Q.dt_b[b] : Q.dt);
     const double UL = Q.UL[b];
     const double S0 = Q.H7 ? 0.0 : Q.S0[b];
     const int src_cut = Q.H7 ? 0 : Q.src_cut[b];
     const double *DEp = S_.DE + off, *cEp = S_.cE + off, *mp = S_.um1 + off;
-    ChunkElim<P, kDivRounded> el;
     FaceCarry c;
     c.hm2 = (DEp[j0 - 1] + DEp[j0]) / 2.0;
     c.hm3 = (-cEp[j0 - 1] - cEp[j0]) / 2.0;
@@ -191,6 +196,15 @@ __device__ __forceinline__ void boundary_next_profile(const tg_state_1f &S_, con
         seg_row(c, DEp[j + 1], -cEp[j + 1], false, H1, mp[j], rc, UL, h7, true, A, B, C, f);
         el.push(i, C, B, A, f);
     }
+}
+
+__device__ __forceinline__ void boundary_finish(const tg_state_1f &S_, const SegWork &W, int64_t b, int k, int side,
+                                                const ChunkElim<8, kDivRounded> &el, const double *y_of_lane) {
+    constexpr int P = 8;
+    const int S = (int)(S_.n / kSeg);
+    const int jb = (k + 1) * kSeg;
+    double *h = W.halo + kHaloQ * (b * (S - 1) + k);
+    const int lane_r = (side ? jb : jb - P) / P;
     const double y = y_of_lane[lane_r];
     const double yl = y_of_lane[lane_r - 1];
     if (side == 0) {
@@ -216,7 +230,7 @@ __device__ __forceinline__ void boundary_next_profile(const tg_state_1f &S_, con
 // PHASE 2: the second half of one iteration and, for profiles that go on, the first half of the next in the same
 //          wavefront: D, c, u_{m-1} and the new profile are in registers already, so the next first half reads only the
 //          profile's EWMA memory (80 instead of 115 bytes per point and iteration).  The two points of the new profile
-//          that an edge lane needs from the neighbouring segment come from the reduce kernel (boundary_next_profile).
+//          that an edge lane needs from the neighbouring segment come from the reduce kernel (boundary_sweep, boundary_finish).
 // wavefronts per SIMD: three (<= 168 registers) and four (<= 128) for the two halves; the combined kernel needs 216
 // registers, and with them at two per SIMD it measured 17 % faster than with 168 and 48 of them spilled
 // ARR: H1 or H7 come as arrays (otherwise H1 = 1 and H7 is the box source of the profile: no loads).
@@ -657,6 +671,25 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next, in
         return;
     }
     const int t = g.t();
+    // Another iteration follows in this call: one thread per side of a segment boundary prepares what the kernel that does
+    // the second half of this iteration and the first half of the next needs there (boundary_sweep, boundary_values).
+    // Everything this takes from memory is fetched here, before the kernel's first store.
+    const bool edge = next && t < 2 * (S - 1);
+    ChunkElim<P, kDivRounded> eb;
+    double bv[8];
+    if (edge) {
+        if ((t & 1) == 0) boundary_values(S_, b, t >> 1, bv);
+        boundary_sweep(S_, Q, b, t >> 1, t & 1, eb);
+    }
+    double seg_ss = 0.0, seg_mx = 0.0;      // residual partial sums of the segments
+    int it0 = 0;
+    if (t == 0) {
+        for (int s = 0; s < S; ++s) {
+            seg_ss += W.ss[b * S + s];
+            seg_mx = fmax(seg_mx, W.mx[b * S + s]);
+        }
+        it0 = S_.iters[b];
+    }
     ChunkElim<P, kDivRounded> el;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -693,24 +726,23 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next, in
 #pragma unroll
         for (int i = 0; i < P; ++i) yl[t * P + i] = y[i];
         __syncthreads();
-        if (t < 2 * (S - 1)) {
-            if ((t & 1) == 0) boundary_snapshot(S_, W, b, t >> 1);
-            boundary_next_profile(S_, Q, W, b, t >> 1, t & 1, yl);
+        if (edge) {
+            if ((t & 1) == 0) {
+                double *h = W.halo + kHaloQ * (b * (S - 1) + (t >> 1));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) h[q] = bv[q];
+            }
+            boundary_finish(S_, W, b, t >> 1, t & 1, eb, yl);
         }
     }
 
     // residual norm of the profile from the segments' partial sums (tango/fieldgroups.py:140, tango/solver.py:464-470)
     if (t == 0) {
-        double ss = 0.0, mx = 0.0;
-        for (int s = 0; s < S; ++s) {
-            ss += W.ss[b * S + s];
-            mx = fmax(mx, W.mx[b * S + s]);
-        }
+        const double ss = seg_ss, mx = seg_mx;
         if (mode == kRetry) {       // the first attempt's matrix decided about convergence (tango/solver.py:464-470)
             W.flag[b] = 1;
         } else {
             const double rms = sqrt(1.0 / (double)n * (ss / (mx * mx)));
-            const int it0 = S_.iters[b];
             if (S_.err && it0 < S_.err_stride) S_.err[b * S_.err_stride + it0] = rms;
             W.flag[b] = (!Q.fixed_count && rms < Q.tol) ? 2 : 1;
         }
