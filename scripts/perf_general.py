@@ -9,7 +9,7 @@ st = torch.cuda.current_stream().cuda_stream
 nb, n = 65536, 512
 ens = shestakov_ensemble(nb, n)
 x = ens['x']
-for mode in ('builtin', 'geometry', 'external', 'external+geometry', 'tread'):
+for mode in ('builtin', 'geometry', 'external', 'external+arrays', 'external+geometry', 'tread'):
     E = OneFieldEnsemble(ens, a_turb=0.3, a_prof=1.0, fixed_count=True, keep_err=False)
     q = E.params
     keep = []
@@ -22,6 +22,10 @@ for mode in ('builtin', 'geometry', 'external', 'external+geometry', 'tread'):
         fl.set(np.full((nb, n), 0.3))
         E.uE.set(ens['u0'])
         q.flux_model, q.flux = H.FLUX_EXTERNAL, fl.ptr
+    if 'arrays' in mode:        # H1 and H7 as arrays, as Solver's external-flux path passes them
+        h1 = H.DeviceArray.from_host(np.ones(n)); h7 = H.DeviceArray.from_host(np.where(x < 0.1, 1.0, 0.0))
+        keep += [h1, h7]
+        q.H1, q.H7, q.h7_stride = h1.ptr, h7.ptr, 0
     if mode == 'tread':
         q.pseudo_time, q.tread_lightly, q.tread_inner_count, q.tread_max_change = 1, 1, n // 2, 0.2
     for _ in range(3):

@@ -1144,26 +1144,6 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                 }
             }
         }
-        // H1 and H7 of this lane's rows.  Arrays for them exist only in the GENERAL form (the launcher sends such calls
-        // there); their loads are issued, and waited for, before the first store of the launch: a wait for a load that
-        // follows stores also waits for those stores to reach memory.
-        double H1v[GENERAL ? P : 1], h7v[GENERAL ? P : 1];
-        if constexpr (GENERAL) {
-#pragma unroll
-            for (int i = 0; i < P; ++i) {
-                const int j = j0 + i;
-                const int jc = (FULL || j < n) ? j : n - 1;
-                H1v[i] = Q.H1 ? Q.H1[jc] : 1.0;
-                h7v[i] = Q.H7 ? Q.H7[b * Q.h7_stride + jc] : ((j < src_cut) ? S0 : 0.0);
-            }
-            if constexpr (EARLY) {
-#pragma unroll
-                for (int i = 0; i < P; ++i) {
-                    landed(H1v[i]);
-                    landed(h7v[i]);
-                }
-            }
-        }
         if constexpr (EARLY) {
             if (!Q.frozen_turb) store_state(false, true);
         }
@@ -1235,10 +1215,15 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             const double hp3 = (h3c + h3n) / 2.0;
             double bp = 0.5;
             if (!half_everywhere) bp = fbeta_point<DIV>(hp2, hp3, rc.dx);
+            // H1 and H7 come as arrays in the GENERAL form only (the launcher sends such calls there).  The built-in form
+            // thus has no load after its first store: a wait for such a load would also wait for the stores before it to
+            // reach memory (the general single-iteration form pays that: holding the sixteen values in registers from before
+            // its early stores costs it more in spills, measured 0.63 against 0.59 ms).
             double H1 = 1.0, h7 = (j < src_cut) ? S0 : 0.0;
             if constexpr (GENERAL) {
-                H1 = H1v[i];
-                h7 = h7v[i];
+                const int jc = valid ? j : n - 1;
+                H1 = Q.H1 ? Q.H1[jc] : 1.0;
+                h7 = Q.H7 ? Q.H7[b * Q.h7_stride + jc] : h7;
             }
             double A, B, C, f;
             fd_row<EXACT>(last, H1, um1[i], rc, UL, hm2, hm3, bm, hp2, hp3, bp, 0.0, 0.0, h7, A, B, C, f);
