@@ -46,11 +46,11 @@ def main():
                 continue
             # the segmented form's k iterations per call are a chain: k reduce kernels, k - 1 combined kernels, one of the rest
             times = 1
-            if k > 1 and 'picard_seg_kernel<2>' in name:
+            if k > 1 and 'picard_seg_kernel<2' in name:
                 times = k - 1
             elif k > 1 and 'picard_seg_reduce_kernel' in name:
                 times = k
-            elif k == 1 and 'picard_seg_kernel<2>' in name:
+            elif k == 1 and 'picard_seg_kernel<2' in name:
                 continue
             if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
                 total += times * (2 * c['FETCH_SIZE'][1] + c['WRITE_SIZE'][1]) * 1024

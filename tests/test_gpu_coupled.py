@@ -281,3 +281,32 @@ def test_threefield_random_problems_vs_oracle(tango, seed):
         for lab, ref in (('n', n), ('pi', pi), ('pe', pe)):
             assert relerr(s.profiles[lab][b], ref) < bar, (seed, b, lab, N, dt)
         assert np.allclose(s.errHistory[b, :its], err[:its], rtol=1e-6, atol=1e-11), (seed, b)
+
+
+def test_threefield_full_size_properties(tango):
+    """16 384 x 512 (the three-field benchmark size): valid results, a scattered subset stepped alone reproduces its
+    members of the full ensemble bit for bit (batch independence), and members against the CPU oracle."""
+    from tango_amd.ensemble import ThreeFieldEnsemble, threefield_ensemble
+    nb, N, its = 16384, 512, 4
+    ens = threefield_ensemble(nb, N)
+    E = ThreeFieldEnsemble(ens, max_iter=its, fixed_count=True)
+    E.step(iters=its)
+    u = [a.to_host() for a in E.u]
+    assert all(np.all(np.isfinite(a)) and np.all(a >= 0) for a in u) and not np.any(E.status.to_host() & 6)
+    assert np.all(E.iters.to_host() == its)
+    sel = np.array([0, 1, 127, 8192, 16383])
+    sub = {k: (v[sel] if k in ('u0', 'nu0', 'bc') else v) for k, v in ens.items()}
+    E2 = ThreeFieldEnsemble(sub, max_iter=its, fixed_count=True)
+    E2.step(iters=its)
+    for k in range(3):
+        assert np.array_equal(E2.u[k].to_host(), u[k][sel])
+        assert np.array_equal(E2.DE[k].to_host(), E.DE[k].to_host()[sel])
+    assert np.array_equal(E2.err.to_host(), E.err.to_host()[sel])
+    for i in (0, 2, 4):
+        b = sel[i]
+        ic = ens['u0'][b]
+        (n, pi, pe), it, err = orc.run_3f(ic, ic, ic, 1e6, ens['dx'], tuple(ens['bc'][b]), ens['nu0'][b], ens['x'], 0.3, 0.3, 1e-30, its,
+                                          fixed_count=True)
+        for k, ref in enumerate((n, pi, pe)):
+            assert relerr(u[k][b], ref) < TOL, (b, k)
+        assert np.allclose(E.err.to_host()[b, :its], err[:its], rtol=1e-6, atol=1e-11)

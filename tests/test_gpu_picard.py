@@ -387,6 +387,34 @@ def test_full_size_properties(tango):
     assert np.max(np.abs(lin) / scale) < 1e-12
 
 
+def test_full_size_properties_long_profiles(tango):
+    """4 096 x 8192 (the fine-grid benchmark size, segmented form of the step): three iterations in one call against
+    a scattered subset stepped alone one iteration per call (batch independence and chain = single calls, bit for bit),
+    and two members against the CPU oracle."""
+    from tango_amd.ensemble import OneFieldEnsemble, shestakov_ensemble
+    nb, N, its = 4096, 8192, 3
+    ens = shestakov_ensemble(nb, N)
+    E = OneFieldEnsemble(ens, a_prof=0.3, max_iter=its, fixed_count=True, keep_err=True)
+    E.step(iters=its)
+    u = E.u.to_host()
+    assert np.all(np.isfinite(u)) and np.all(u >= 0) and not np.any(E.status.to_host() & 6)
+    assert np.all(E.iters.to_host() == its)
+    sel = np.array([0, 1, 255, 2048, 4095])
+    sub = {k: (v[sel] if k in ('u0', 'nL', 'S0', 'delta') else v) for k, v in ens.items()}
+    E2 = OneFieldEnsemble(sub, a_prof=0.3, max_iter=its, fixed_count=True)
+    for _ in range(its):
+        E2.step()
+    assert np.array_equal(E2.u.to_host(), u[sel])
+    assert np.array_equal(E2.DE.to_host(), E.DE.to_host()[sel])
+    assert np.array_equal(E2.err.to_host(), E.err.to_host()[sel])
+    H7 = orc.shestakov_source(ens['x'], sub['S0'], sub['delta'])
+    for i in (0, 3):
+        st = orc.State1F(sub['u0'][i])
+        for _ in range(its):
+            orc.picard_step_1f(st, 1e4, ens['dx'], sub['nL'][i], np.ones(N), H7[i], 0.3, 0.3)
+        assert relerr(u[sel[i]], st.u) < TOL
+
+
 @pytest.mark.parametrize('N,nb', [(512, 9), (500, 5), (100, 7), (1000, 2)])
 def test_multi_iteration_launch_equals_single_launches(tango, N, nb):
     """k iterations in one launch (profiles register-resident in between) against k launches of one iteration:
