@@ -212,7 +212,10 @@ typedef struct {
     const double *UL;    /* (nb,) right boundary values */
     const double *dt_b;  /* optional (nb,) per-profile pseudo-timestep */
     const double *H1;    /* optional (n,) shared; NULL = 1 */
-    const double *H7;    /* optional source array, stride h7_stride; NULL = box source below */
+    const double *H7;    /* optional source array, stride h7_stride; NULL = box source below
+                          * (a call that gives H1 or H7 as arrays takes the general form of the kernel, like one with
+                          * geometry arrays or an external flux; with both NULL and the built-in Cartesian flux it takes
+                          * the leaner built-in form) */
     int64_t h7_stride;
     const double *S0;        /* (nb,) box source used when H7 == NULL: H7_j = S0[b] for j < src_cut[b], else 0 */
     const int32_t *src_cut;  /* (nb,) number of grid points with x < delta (the grid is increasing) */
