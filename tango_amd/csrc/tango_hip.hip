@@ -775,13 +775,18 @@ __device__ __forceinline__ void smooth_flux(double *row, int n, int j0, int h, d
 // registers between those iterations (u, the three EWMA memories and u_{m-1}: 42 doubles per lane), so the
 // state crosses HBM once per launch instead of once per iteration; the convergence test, the freeze of a
 // converged profile and the residual history are per iteration, exactly as with one iteration per launch.
-// GENERAL = false is the Cartesian case with the built-in flux (no geometry arrays, no external flux): H2 and H3
-// are then the EWMA memories themselves and need no registers of their own.
+// GEN = 0 is the Cartesian case with the built-in flux (no geometry arrays, no external flux): H2 and H3 are then the
+// EWMA memories themselves and need no registers of their own.  GEN = 1 adds what a run coupled to a turbulence code
+// needs (external flux array, geometry arrays, H1/H7 arrays); GEN = 2 adds pseudo-timestep control, flux smoothing, the
+// flux multiplier and the power-law flux, whose loop-carried values and long code would otherwise cost the coupled run
+// its registers.
 // MULTI = false compiles the single-iteration form (no loop, no selects on `done`).
 
-template <int P, class G, bool FULL, bool GENERAL, bool MULTI>
+template <int P, class G, bool FULL, int GEN, bool MULTI>
 __global__ void __launch_bounds__(G::kBlock ? G::T : 256, (G::kBlock && G::T > 512) ? 4 : 2)   // two wavefronts per SIMD: <= 256 registers
 picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
+    constexpr bool GENERAL = GEN != 0;
+    constexpr bool EXTRAS = GEN == 2;      // pseudo-timestep control, smoothing, flux multiplier, power-law flux
     extern __shared__ double lds[];
     G g(lds);
     const int64_t b = (int64_t)blockIdx.x * G::profiles_per_block(blockDim.x) + g.profile_in_block();
@@ -984,7 +989,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         // over the wavefront (workgroup), the loop is left as soon as `done` is set, and `seeded` is a branch.
         constexpr bool kShared = !G::kBlock && G::T < 64;
         const bool hold = kShared && done;
-        if constexpr (GENERAL) {
+        if constexpr (EXTRAS) {
             if (Q.pseudo_time) {
                 // the previous iterate takes the u_{m-1} slot (tango/solver.py:198-201); treadInitially's short
                 // pseudo-timestep for a profile's first iterations (:210-215)
@@ -1023,7 +1028,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             // Flux smoothing (tango/lodestro_method.py:359-362): the flux of the whole profile has to exist before any point
             // is split, so the built-in model is evaluated into fl first; from there on it is treated like an outside flux.
             bool have_flux = external;
-            if constexpr (GENERAL) {
+            if constexpr (EXTRAS) {
                 const bool power = Q.flux_model == TG_FLUX_POWER;
                 if (Q.smooth_window > 1 || Q.flux_mult || power) {
                     if (!external) {
@@ -1253,7 +1258,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
 
         double xt[P];
         el.finish(g, xt);
-        if constexpr (!GENERAL) {
+        if constexpr (!EXTRAS) {
 #pragma unroll
             for (int i = 0; i < P; ++i) x[i] = xt[i];
             singular = el.singular;
@@ -1370,8 +1375,8 @@ struct Picard1fLauncher {
                        reinterpret_cast<uintptr_t>(q->gradx) | reinterpret_cast<uintptr_t>(q->gxx_turb) |
                        reinterpret_cast<uintptr_t>(q->gradx_turb) | reinterpret_cast<uintptr_t>(q->iterates);
         const bool full = (n == P * G::T) && (al & 15) == 0;
-        const bool general = q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->pseudo_time || q->tread_lightly ||
-                             q->smooth_window > 1 || q->flux_mult || q->H1 || q->H7;
+        const bool extras = q->flux_model == TG_FLUX_POWER || q->pseudo_time || q->tread_lightly || q->smooth_window > 1 || q->flux_mult;
+        const bool general = extras || q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->H1 || q->H7;
         const bool multi = q->iters_per_launch > 1;
         if (kWaveCoop<P, G, true> && full) lds += (size_t)(block / 64) * kCoopTiles<G> * WaveTile<8>::kDoubles * sizeof(double);
         tg_params_1f qs = *q;
@@ -1385,18 +1390,24 @@ struct Picard1fLauncher {
         }
         q = &qs;
 #define TG_LAUNCH_1F(F, GEN, M) hipLaunchKernelGGL((picard_1f_kernel<P, G, F, GEN, M>), dim3(grid), dim3(block), lds, s, *st, *q)
-        if (general && multi) {
-            if (full) TG_LAUNCH_1F(true, true, true);
-            else TG_LAUNCH_1F(false, true, true);
+        if (extras && multi) {
+            if (full) TG_LAUNCH_1F(true, 2, true);
+            else TG_LAUNCH_1F(false, 2, true);
+        } else if (extras) {
+            if (full) TG_LAUNCH_1F(true, 2, false);
+            else TG_LAUNCH_1F(false, 2, false);
+        } else if (general && multi) {
+            if (full) TG_LAUNCH_1F(true, 1, true);
+            else TG_LAUNCH_1F(false, 1, true);
         } else if (general) {
-            if (full) TG_LAUNCH_1F(true, true, false);
-            else TG_LAUNCH_1F(false, true, false);
+            if (full) TG_LAUNCH_1F(true, 1, false);
+            else TG_LAUNCH_1F(false, 1, false);
         } else if (multi) {
-            if (full) TG_LAUNCH_1F(true, false, true);
-            else TG_LAUNCH_1F(false, false, true);
+            if (full) TG_LAUNCH_1F(true, 0, true);
+            else TG_LAUNCH_1F(false, 0, true);
         } else {
-            if (full) TG_LAUNCH_1F(true, false, false);
-            else TG_LAUNCH_1F(false, false, false);
+            if (full) TG_LAUNCH_1F(true, 0, false);
+            else TG_LAUNCH_1F(false, 0, false);
         }
 #undef TG_LAUNCH_1F
         return launch_check();
