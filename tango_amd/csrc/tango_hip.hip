@@ -1149,6 +1149,24 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                 }
             }
         }
+        // The coupled-run form has the registers to fetch H1 and H7 of its rows before its early stores (a wait for a load
+        // that follows stores also waits for those stores to reach memory); the form with the extras keeps them in the loop.
+        constexpr bool HOIST = (GEN == 1) && EARLY;
+        double H1v[HOIST ? P : 1], h7v[HOIST ? P : 1];
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int j = j0 + i;
+                const int jc = (FULL || j < n) ? j : n - 1;
+                H1v[i] = Q.H1 ? Q.H1[jc] : 1.0;
+                h7v[i] = Q.H7 ? Q.H7[b * Q.h7_stride + jc] : ((j < src_cut) ? S0 : 0.0);
+            }
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                landed(H1v[i]);
+                landed(h7v[i]);
+            }
+        }
         if constexpr (EARLY) {
             if (!Q.frozen_turb) store_state(false, true);
         }
@@ -1225,7 +1243,10 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             // reach memory (the general single-iteration form pays that: holding the sixteen values in registers from before
             // its early stores costs it more in spills, measured 0.63 against 0.59 ms).
             double H1 = 1.0, h7 = (j < src_cut) ? S0 : 0.0;
-            if constexpr (GENERAL) {
+            if constexpr (HOIST) {
+                H1 = H1v[i];
+                h7 = h7v[i];
+            } else if constexpr (GENERAL) {
                 const int jc = valid ? j : n - 1;
                 H1 = Q.H1 ? Q.H1[jc] : 1.0;
                 h7 = Q.H7 ? Q.H7[b * Q.h7_stride + jc] : h7;
