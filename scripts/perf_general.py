@@ -9,7 +9,7 @@ st = torch.cuda.current_stream().cuda_stream
 nb, n = 65536, 512
 ens = shestakov_ensemble(nb, n)
 x = ens['x']
-for mode in ('builtin', 'geometry', 'external', 'external+arrays', 'external+geometry', 'tread'):
+for mode in ('builtin', 'geometry', 'external', 'external+arrays', 'external+arrays+smooth', 'external+geometry', 'tread'):
     E = OneFieldEnsemble(ens, a_turb=0.3, a_prof=1.0, fixed_count=True, keep_err=False)
     q = E.params
     keep = []
@@ -26,6 +26,8 @@ for mode in ('builtin', 'geometry', 'external', 'external+arrays', 'external+geo
         h1 = H.DeviceArray.from_host(np.ones(n)); h7 = H.DeviceArray.from_host(np.where(x < 0.1, 1.0, 0.0))
         keep += [h1, h7]
         q.H1, q.H7, q.h7_stride = h1.ptr, h7.ptr, 0
+    if 'smooth' in mode:        # a five-point flux smoother inside the kernel, as the reference's GENE drivers use
+        q.smooth_window = 5
     if mode == 'tread':
         q.pseudo_time, q.tread_lightly, q.tread_inner_count, q.tread_max_change = 1, 1, n // 2, 0.2
     for _ in range(150):         # long enough for the GPU's clock to come up (50 ms of launches)

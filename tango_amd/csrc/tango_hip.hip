@@ -777,16 +777,16 @@ __device__ __forceinline__ void smooth_flux(double *row, int n, int j0, int h, d
 // converged profile and the residual history are per iteration, exactly as with one iteration per launch.
 // GEN = 0 is the Cartesian case with the built-in flux (no geometry arrays, no external flux): H2 and H3 are then the
 // EWMA memories themselves and need no registers of their own.  GEN = 1 adds what a run coupled to a turbulence code
-// needs (external flux array, geometry arrays, H1/H7 arrays); GEN = 2 adds pseudo-timestep control, flux smoothing, the
-// flux multiplier and the power-law flux, whose loop-carried values and long code would otherwise cost the coupled run
-// its registers.
+// needs (external flux array, geometry arrays, H1/H7 arrays, flux smoothing, flux multiplier); GEN = 2 adds pseudo-timestep
+// control and the power-law flux, whose loop-carried values and long code would otherwise cost the coupled run its
+// registers.
 // MULTI = false compiles the single-iteration form (no loop, no selects on `done`).
 
 template <int P, class G, bool FULL, int GEN, bool MULTI>
 __global__ void __launch_bounds__(G::kBlock ? G::T : 256, (G::kBlock && G::T > 512) ? 4 : 2)   // two wavefronts per SIMD: <= 256 registers
 picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     constexpr bool GENERAL = GEN != 0;
-    constexpr bool EXTRAS = GEN == 2;      // pseudo-timestep control, smoothing, flux multiplier, power-law flux
+    constexpr bool EXTRAS = GEN == 2;      // pseudo-timestep control, power-law flux
     extern __shared__ double lds[];
     G g(lds);
     const int64_t b = (int64_t)blockIdx.x * G::profiles_per_block(blockDim.x) + g.profile_in_block();
@@ -1028,8 +1028,8 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             // Flux smoothing (tango/lodestro_method.py:359-362): the flux of the whole profile has to exist before any point
             // is split, so the built-in model is evaluated into fl first; from there on it is treated like an outside flux.
             bool have_flux = external;
-            if constexpr (EXTRAS) {
-                const bool power = Q.flux_model == TG_FLUX_POWER;
+            if constexpr (GENERAL) {
+                const bool power = EXTRAS && Q.flux_model == TG_FLUX_POWER;
                 if (Q.smooth_window > 1 || Q.flux_mult || power) {
                     if (!external) {
 #pragma unroll
@@ -1041,7 +1041,8 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                             const double pp = (i == P - 1) ? wr : ue[i < P - 1 ? i + 1 : 0];
                             const double dpdx = ddx_edge1_point<EXACT>(pm, ue[i], pp, first, last, rc);
                             // examples/stripped_down_tango_example.py:60-64: Deff = |(dn/dx / n)^q|, Gamma = -Deff dn/dx
-                            fl[i] = power ? -(pow(fabs(dpdx / ue[i]), Q.flux_power) * dpdx) : quot<DIV>(-(dpdx * dpdx * dpdx), ue[i] * ue[i]);
+                            if constexpr (EXTRAS) fl[i] = power ? -(pow(fabs(dpdx / ue[i]), Q.flux_power) * dpdx) : quot<DIV>(-(dpdx * dpdx * dpdx), ue[i] * ue[i]);
+                            else fl[i] = quot<DIV>(-(dpdx * dpdx * dpdx), ue[i] * ue[i]);
                         }
                     }
                     if (Q.flux_mult) {      // flux-model decorators (taper, noise) act on the flux the model returns
@@ -1396,8 +1397,9 @@ struct Picard1fLauncher {
                        reinterpret_cast<uintptr_t>(q->gradx) | reinterpret_cast<uintptr_t>(q->gxx_turb) |
                        reinterpret_cast<uintptr_t>(q->gradx_turb) | reinterpret_cast<uintptr_t>(q->iterates);
         const bool full = (n == P * G::T) && (al & 15) == 0;
-        const bool extras = q->flux_model == TG_FLUX_POWER || q->pseudo_time || q->tread_lightly || q->smooth_window > 1 || q->flux_mult;
-        const bool general = extras || q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->H1 || q->H7;
+        const bool extras = q->flux_model == TG_FLUX_POWER || q->pseudo_time || q->tread_lightly;
+        const bool general = extras || q->flux_model != TG_FLUX_SHESTAKOV || q->Vprime || q->gxx_turb || q->gradx_turb || q->H1 || q->H7 ||
+                             q->smooth_window > 1 || q->flux_mult;
         const bool multi = q->iters_per_launch > 1;
         if (kWaveCoop<P, G, true> && full) lds += (size_t)(block / 64) * kCoopTiles<G> * WaveTile<8>::kDoubles * sizeof(double);
         tg_params_1f qs = *q;
