@@ -753,17 +753,35 @@ __device__ __forceinline__ void smooth_flux(double *row, int n, int j0, int h, d
         row[e + (e >> 3)] = fl[i];
     }
     barrier();
+    // The lane's P windows advance together, one window position per pass: P independent LDS reads and P additions per
+    // pass instead of a chain of dependent reads per point.  A point whose (shrunken) window does not reach a position
+    // adds an exact zero there, so every window is still summed left to right over its own elements.
+    int hh[P];
+    double sum[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int j = j0 + i;
-        if (j < n) {
-            int hh = h;
-            hh = j < hh ? j : hh;
-            hh = (n - 1 - j) < hh ? (n - 1 - j) : hh;
-            double sum = 0.0;
-            for (int k = j - hh; k <= j + hh; ++k) sum += row[k + (k >> 3)];
-            fl[i] = sum / (double)(2 * hh + 1);
+        int w = h;
+        w = j < w ? j : w;
+        w = (n - 1 - j) < w ? (n - 1 - j) : w;
+        hh[i] = (j < n) ? w : -1;
+        sum[i] = 0.0;
+    }
+    for (int d = -h; d <= h; ++d) {
+        const int ad = d < 0 ? -d : d;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            int k = j0 + i + d;
+            k = k < 0 ? 0 : (k > n - 1 ? n - 1 : k);
+            const double v = row[k + (k >> 3)];
+            sum[i] += (ad <= hh[i]) ? v : 0.0;
         }
+    }
+    // the quotient by the window's length: the short division sequence gives the correctly rounded quotient for these
+    // operands, i.e. what the division itself gives (tg_comm.h)
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        if (hh[i] >= 0) fl[i] = quot<kDivRounded>(sum[i], (double)(2 * hh[i] + 1));
     }
     barrier();
 }
@@ -1054,8 +1072,16 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                         }
                     }
                     if (Q.smooth_window > 1) {
-                        double *row = lds + Q.reserved_;
-                        if constexpr (!G::kBlock) row += wave_in_block() * 576 + ((threadIdx.x & 63) / G::T) * (G::T * 9);
+                        // the padded row of this profile: in the wavefront's own tiles where it has some (they are idle while
+                        // the flux is smoothed, and a row area of its own would cost a resident workgroup per CU), else in the
+                        // area the launcher reserved
+                        double *row;
+                        if constexpr (COOP_T && !G::kBlock) {
+                            row = lds + wave_in_block() * NT * Tile::kDoubles + ((threadIdx.x & 63) / G::T) * (G::T * 9);
+                        } else {
+                            row = lds + Q.reserved_;
+                            if constexpr (!G::kBlock) row += wave_in_block() * 576 + ((threadIdx.x & 63) / G::T) * (G::T * 9);
+                        }
                         smooth_flux<P, G>(row, n, j0, (Q.smooth_window - 1) / 2, fl);
                     }
                     have_flux = true;
@@ -1405,10 +1431,14 @@ struct Picard1fLauncher {
         tg_params_1f qs = *q;
         qs.reserved_ = 0;
         if (q->smooth_window > 1) {
-            // one padded row per profile for the flux smoothing, behind the exchange area and the tiles
+            // one padded row per profile for the flux smoothing: behind the exchange area and the tiles, except where a
+            // wavefront owns whole profiles and has tiles: there the row lies in them
             if (n > 4096) return fail(TG_ERR_UNSUPPORTED, "flux smoothing inside the fused step needs n <= 4096%s");
-            qs.reserved_ = (int32_t)(lds / sizeof(double));
-            lds += sizeof(double) * (G::kBlock ? (size_t)G::T * P * 9 / 8 + 8 : (size_t)(block / 64) * 576);
+            const bool in_tiles = !G::kBlock && kWaveCoop<P, G, true> && full;
+            if (!in_tiles) {
+                qs.reserved_ = (int32_t)(lds / sizeof(double));
+                lds += sizeof(double) * (G::kBlock ? (size_t)G::T * P * 9 / 8 + 8 : (size_t)(block / 64) * 576);
+            }
             if (lds > max_lds_bytes()) return fail(TG_ERR_UNSUPPORTED, "flux smoothing: not enough LDS for this grid size%s");
         }
         q = &qs;
