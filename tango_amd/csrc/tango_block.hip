@@ -388,17 +388,18 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     // the Dirichlet row do not use theirs.
     bool half = true;
     {
-        auto dominated = [&](double h2, double h3) { return (h3 != 0.0) && (h2 >= 0.5 * fabs(h3 * rc.dx)); };
+        // (plain & and |: evaluated for every face, no branch per face)
+        auto dominated = [&](double h2, double h3) { return bool((h3 != 0.0) & (h2 >= 0.5 * fabs(h3 * rc.dx))); };
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            if (!lane_first && (FULL || j0 < n - 1)) half = half && dominated((h2l[s] + DE[s][0]) / 2.0, (h3l[s] + -cE[s][0]) / 2.0);
+            if (!lane_first && (FULL || j0 < n - 1)) half = half & dominated((h2l[s] + DE[s][0]) / 2.0, (h3l[s] + -cE[s][0]) / 2.0);
             double a2 = DE[s][0], a3 = -cE[s][0];
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 const bool used = FULL ? !(i == P - 1 && t == G::T - 1) : (j0 + i < n - 1);
                 const double n2 = (i == P - 1) ? h2r[s] : DE[s][i < P - 1 ? i + 1 : 0];
                 const double n3 = (i == P - 1) ? h3r[s] : -cE[s][i < P - 1 ? i + 1 : 0];
-                half = half && (!used || dominated((a2 + n2) / 2.0, (a3 + n3) / 2.0));
+                half = half & (!used | dominated((a2 + n2) / 2.0, (a3 + n3) / 2.0));
                 a2 = n2;
                 a3 = n3;
             }

@@ -1230,7 +1230,8 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         // Dirichlet row do not use theirs.
         bool half = true;
         {
-            auto dominated = [&](double h2, double h3) { return (h3 != 0.0) && (h2 >= 0.5 * fabs(h3 * rc.dx)); };
+            // (plain & and |: evaluated for every face, no branch per face)
+            auto dominated = [&](double h2, double h3) { return bool((h3 != 0.0) & (h2 >= 0.5 * fabs(h3 * rc.dx))); };
             if (!lane_first && (FULL || j0 < n - 1)) half = dominated((h2l + h2first) / 2.0, (h3l + h3first) / 2.0);
             double a2 = h2first, a3 = h3first;
 #pragma unroll
@@ -1239,7 +1240,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                 const bool used = FULL ? !(i == P - 1 && t == G::T - 1) : (j < n - 1);
                 const double n2 = (i == P - 1) ? h2r : H2at(i < P - 1 ? i + 1 : 0);
                 const double n3 = (i == P - 1) ? h3r : H3at(i < P - 1 ? i + 1 : 0);
-                half = half && (!used || dominated((a2 + n2) / 2.0, (a3 + n3) / 2.0));
+                half = half & (!used | dominated((a2 + n2) / 2.0, (a3 + n3) / 2.0));
                 a2 = n2;
                 a3 = n3;
             }

@@ -334,7 +334,8 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         // point carries H2 = H3 = 0 and its weight multiplies zeros; the Dirichlet row does not use its right face.
         bool half = true;
         {
-            auto dominated = [&](double h2, double h3) { return (h3 != 0.0) && (h2 >= 0.5 * fabs(h3 * rc.dx)); };
+            // (plain & and |: evaluated for every face, no branch per face)
+            auto dominated = [&](double h2, double h3) { return bool((h3 != 0.0) & (h2 >= 0.5 * fabs(h3 * rc.dx))); };
             if (!first_lane) half = dominated((h2l + DE[0]) / 2.0, (h3l - cE[0]) / 2.0);
             double a2 = DE[0], a3 = -cE[0];
 #pragma unroll
@@ -342,7 +343,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
                 const bool used = !((i == P - 1) && last_lane);
                 const double n2 = (i == P - 1) ? h2r : DE[i < P - 1 ? i + 1 : 0];
                 const double n3 = (i == P - 1) ? h3r : -cE[i < P - 1 ? i + 1 : 0];
-                half = half && (!used || dominated((a2 + n2) / 2.0, (a3 + n3) / 2.0));
+                half = half & (!used | dominated((a2 + n2) / 2.0, (a3 + n3) / 2.0));
                 a2 = n2;
                 a3 = n3;
             }
