@@ -1266,10 +1266,9 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             const double hp3 = (h3c + h3n) / 2.0;
             double bp = 0.5;
             if (!half_everywhere) bp = fbeta_point<DIV>(hp2, hp3, rc.dx);
-            // H1 and H7 come as arrays in the GENERAL form only (the launcher sends such calls there).  The built-in form
-            // thus has no load after its first store: a wait for such a load would also wait for the stores before it to
-            // reach memory (the general single-iteration form pays that: holding the sixteen values in registers from before
-            // its early stores costs it more in spills, measured 0.63 against 0.59 ms).
+            // H1 and H7 come as arrays in the general forms only (the launcher sends such calls there), so that the built-in
+            // form has no load after its first store (a wait for such a load would also wait for the stores before it to
+            // reach memory); the coupled-run form has fetched them ahead of its early stores (HOIST).
             double H1 = 1.0, h7 = (j < src_cut) ? S0 : 0.0;
             if constexpr (HOIST) {
                 H1 = H1v[i];
