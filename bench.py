@@ -13,7 +13,7 @@ check) of every profile of the ensemble, all profiles forced active.  Configurat
 steps in one kernel launch with every profile held in registers in between: the arithmetic, the per-iteration
 convergence test and the residual history are those of k single launches, only the HBM round trip of the state
 between iterations is gone.  For c4 (default 16) the k iterations of a call are a chain of kernels in which the second
-half of an iteration and the first half of the next share a kernel: every iteration still crosses HBM, with 74 instead
+half of an iteration and the first half of the next share a kernel: every iteration still crosses HBM, with 78 instead
 of 109 bytes per point.
 
 N > 1: one process per GPU.  Started by a launcher (RANK / WORLD_SIZE in the environment, e.g.
@@ -319,8 +319,8 @@ def main():
             if fields == 3:
                 kernel = 'picard_3f_kernel'
             elif segmented and kper > 1:
-                kernel = (f'one call = seg_halo_kernel, picard_seg_kernel<0>, picard_seg_reduce_kernel, then {kper - 1} x (seg_halo_kernel<true>, '
-                          f'picard_seg_kernel<2>, picard_seg_reduce_kernel), picard_seg_kernel<1>')
+                kernel = (f'one call = seg_halo_kernel, picard_seg_kernel<0>, then {kper - 1} x (picard_seg_reduce_kernel, '
+                          f'picard_seg_kernel<2>), picard_seg_reduce_kernel, picard_seg_kernel<1>')
             elif segmented:
                 kernel = 'one call = seg_halo_kernel, picard_seg_kernel<0>, picard_seg_reduce_kernel, picard_seg_kernel<1>'
             else:
