@@ -1,5 +1,7 @@
 """Coupled-field kernels: the pair-coupled (2x2 block) solve, the 3x3 block-tridiagonal solve and the fused
 three-field Picard iteration, against the reference's golden vectors and the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -256,7 +258,7 @@ def test_threefield_ensemble(tango, golden):
         assert relerr(s.profiles['n'][b], n) < TOL and relerr(s.profiles['pi'][b], pi) < TOL and relerr(s.profiles['pe'][b], pe) < TOL
 
 
-@pytest.mark.parametrize('seed', range(10))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('TANGO_RANDOM_SEEDS_3F', '10'))))      # more seeds for a sweep by hand
 def test_threefield_random_problems_vs_oracle(tango, seed):
     """Randomly drawn grids, collision frequencies, boundary values, EWMA parameters and timesteps, a fixed number of
     iterations: the fused three-field kernel (one wavefront or one workgroup per profile, full and ragged grids)

@@ -282,7 +282,7 @@ def test_fine_grid_vs_reference(tango, golden):
     assert np.allclose(E.err.to_host()[0], g['N8192_err'], rtol=1e-4)
 
 
-@pytest.mark.parametrize('seed', range(48))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('TANGO_RANDOM_SEEDS', '48'))))      # more seeds for a sweep by hand
 def test_random_problems_vs_oracle(tango, seed):
     """Randomly drawn grids, timesteps, EWMA parameters, theta parameters (so that every branch of the theta rule and
     of the upwinding weight occurs), sources and initial profiles, several iterations per launch or one: the fused
