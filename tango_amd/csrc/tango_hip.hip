@@ -1041,8 +1041,18 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                 if (Q.gxx_turb) load_shared(Q.gxx_turb, gxt, Q.gradx_turb, grt);
                 else if (Q.gradx_turb) load_shared(Q.gradx_turb, grt, nullptr, nullptr);
             }
-            const double wl = g.from_left(ue[P - 1], 1, 0.0);
-            const double wr = g.from_right(ue[0], 1, 0.0);
+            // (a workgroup exchanges through LDS: one exchange of both values costs one pair of barriers instead of two)
+            double wl, wr;
+            if constexpr (G::kBlock) {
+                const double v[2] = {ue[P - 1], ue[0]};
+                double lq[2], rq[2];
+                g.template exchange<2>(v, 1, lq, rq);
+                wl = lq[0];
+                wr = rq[1];
+            } else {
+                wl = g.from_left(ue[P - 1], 1, 0.0);
+                wr = g.from_right(ue[0], 1, 0.0);
+            }
             // Flux smoothing (tango/lodestro_method.py:359-362): the flux of the whole profile has to exist before any point
             // is split, so the built-in model is evaluated into fl first; from there on it is treated like an outside flux.
             bool have_flux = external;
@@ -1206,10 +1216,23 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             else return -cE[k];
         };
         const double h2first = H2at(0), h3first = H3at(0), h2last = H2at(P - 1), h3last = H3at(P - 1);
-        const double h2l = g.from_left(h2last, 1, 0.0), h3l = g.from_left(h3last, 1, 0.0);
-        const double h2r = g.from_right(h2first, 1, 0.0), h3r = g.from_right(h3first, 1, 0.0);
-        u[0] = g.from_left(u[P], 1, 0.0);
-        u[P + 1] = g.from_right(u[1], 1, 0.0);
+        double h2l, h3l, h2r, h3r;
+        if constexpr (G::kBlock) {      // six halo values in one exchange: one pair of barriers instead of six
+            const double v[6] = {h2last, h3last, u[P], h2first, h3first, u[1]};
+            double lq[6], rq[6];
+            g.template exchange<6>(v, 1, lq, rq);
+            h2l = lq[0];
+            h3l = lq[1];
+            u[0] = lq[2];
+            h2r = rq[3];
+            h3r = rq[4];
+            u[P + 1] = rq[5];
+        } else {
+            h2l = g.from_left(h2last, 1, 0.0), h3l = g.from_left(h3last, 1, 0.0);
+            h2r = g.from_right(h2first, 1, 0.0), h3r = g.from_right(h3first, 1, 0.0);
+            u[0] = g.from_left(u[P], 1, 0.0);
+            u[P + 1] = g.from_right(u[1], 1, 0.0);
+        }
 
         // Assemble row by row and eliminate at once.  Half-grid slot "m" lies between local points i-1 and i,
         // slot "p" between i and i+1; the p values of row i are the m values of row i+1.
