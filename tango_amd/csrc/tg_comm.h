@@ -73,6 +73,19 @@ __device__ __forceinline__ double dpp_from_lane_above(double v) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
+// The same with zero for the lane at the end (bound_ctrl: a lane without a source receives 0): no select afterwards.
+__device__ __forceinline__ double dpp_from_lane_below_or_zero(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_lane_above_or_zero(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 
 // Exchange between the two halves of a wavefront: lane t receives the value of lane t ^ 32 (one v_permlane32_swap per
 // dword and a select, no trip through the LDS crossbar).
@@ -116,14 +129,22 @@ struct WaveGroup {
     // value held by lane t-h (fill when there is none)
     __device__ double from_left(double v, int h, double fill) const {
         double r;
-        if (LPP == 64 && __builtin_constant_p(h) && h == 1) r = dpp_from_lane_below(v);
-        else r = __shfl_up(v, (unsigned)h, LPP);
+        if (LPP == 64 && __builtin_constant_p(h) && h == 1) {
+            if (__builtin_constant_p(fill) && fill == 0.0) return dpp_from_lane_below_or_zero(v);
+            r = dpp_from_lane_below(v);
+        } else {
+            r = __shfl_up(v, (unsigned)h, LPP);
+        }
         return (t_ >= h) ? r : fill;
     }
     __device__ double from_right(double v, int h, double fill) const {
         double r;
-        if (LPP == 64 && __builtin_constant_p(h) && h == 1) r = dpp_from_lane_above(v);
-        else r = __shfl_down(v, (unsigned)h, LPP);
+        if (LPP == 64 && __builtin_constant_p(h) && h == 1) {
+            if (__builtin_constant_p(fill) && fill == 0.0) return dpp_from_lane_above_or_zero(v);
+            r = dpp_from_lane_above(v);
+        } else {
+            r = __shfl_down(v, (unsigned)h, LPP);
+        }
         return (t_ + h < LPP) ? r : fill;
     }
     // CNT values from the lanes t-h (l) and t+h (r), zeros where there is no such lane
