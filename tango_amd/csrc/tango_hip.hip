@@ -997,6 +997,17 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     // this profile needs no further iteration (uniform over its lane group)
     constexpr bool PACKED = COOP_T && !COOP_ALWAYS;    // wavefronts that may carry profiles that were never active
     bool done = PACKED ? !active : false;
+    // the box source of this lane's rows is the same in every iteration of the launch: formed once and kept (`landed` keeps
+    // the compiler from forming it again in the loop)
+    constexpr bool SRC_KEPT = MULTI && !GENERAL && !G::kBlock && G::T == 64;
+    double src_row[SRC_KEPT ? P : 1];
+    if constexpr (SRC_KEPT) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            src_row[i] = (j0 + i < src_cut) ? S0 : 0.0;
+            landed(src_row[i]);
+        }
+    }
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) {
         if constexpr (!MULTI && !PACKED) done = false;
@@ -1292,7 +1303,9 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             // H1 and H7 come as arrays in the general forms only (the launcher sends such calls there), so that the built-in
             // form has no load after its first store (a wait for such a load would also wait for the stores before it to
             // reach memory); the coupled-run form has fetched them ahead of its early stores (HOIST).
-            double H1 = 1.0, h7 = (j < src_cut) ? S0 : 0.0;
+            double H1 = 1.0, h7;
+            if constexpr (SRC_KEPT) h7 = src_row[i];
+            else h7 = (j < src_cut) ? S0 : 0.0;
             if constexpr (HOIST) {
                 H1 = H1v[i];
                 h7 = h7v[i];
