@@ -997,6 +997,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
     // this profile needs no further iteration (uniform over its lane group)
     constexpr bool PACKED = COOP_T && !COOP_ALWAYS;    // wavefronts that may carry profiles that were never active
     bool done = PACKED ? !active : false;
+    const double inv_n = 1.0 / (double)n;      // (a division: formed once, not in every iteration of the launch)
     // the box source of this lane's rows is the same in every iteration of the launch: formed once and kept (`landed` keeps
     // the compiler from forming it again in the loop)
     constexpr bool SRC_KEPT = MULTI && !GENERAL && !G::kBlock && G::T == 64;
@@ -1337,7 +1338,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         if (attempt == 0) {
             double mxv[1] = {mx}, ssv[1] = {ss};
             g.template max_and_sum<1>(mxv, ssv);
-            rms = sqrt(1.0 / (double)n * quot<DIV>(ssv[0], mxv[0] * mxv[0]));
+            rms = sqrt(inv_n * quot<DIV>(ssv[0], mxv[0] * mxv[0]));
         }
 
         double xt[P];
