@@ -128,9 +128,11 @@ struct WaveGroup {
 
     // value held by lane t-h (fill when there is none)
     __device__ double from_left(double v, int h, double fill) const {
+        // distance 1: a DPP move over the whole wavefront, also where several profiles share it (the first lane of a
+        // group then receives the last lane of the group before it, and drops it)
         double r;
-        if (LPP == 64 && __builtin_constant_p(h) && h == 1) {
-            if (__builtin_constant_p(fill) && fill == 0.0) return dpp_from_lane_below_or_zero(v);
+        if (__builtin_constant_p(h) && h == 1) {
+            if (LPP == 64 && __builtin_constant_p(fill) && fill == 0.0) return dpp_from_lane_below_or_zero(v);
             r = dpp_from_lane_below(v);
         } else {
             r = __shfl_up(v, (unsigned)h, LPP);
@@ -139,8 +141,8 @@ struct WaveGroup {
     }
     __device__ double from_right(double v, int h, double fill) const {
         double r;
-        if (LPP == 64 && __builtin_constant_p(h) && h == 1) {
-            if (__builtin_constant_p(fill) && fill == 0.0) return dpp_from_lane_above_or_zero(v);
+        if (__builtin_constant_p(h) && h == 1) {
+            if (LPP == 64 && __builtin_constant_p(fill) && fill == 0.0) return dpp_from_lane_above_or_zero(v);
             r = dpp_from_lane_above(v);
         } else {
             r = __shfl_down(v, (unsigned)h, LPP);
@@ -206,7 +208,9 @@ struct WaveGroup {
 #pragma unroll
         for (int h = 1; h < LPP; h <<= 1) {
             double sm, rm, dm, pp, rp, dp;
-            if (LPP == 64 && h == 1) {      // nearest neighbours over a whole wavefront: DPP moves
+            if (LPP == 64 && h == 1) {      // nearest neighbours over a whole wavefront: DPP moves (not where profiles share a
+                                            // wavefront: an end lane would multiply ANOTHER profile's value by its zero, and
+                                            // that value may be NaN)
                 sm = dpp_from_lane_below(s), rm = dpp_from_lane_below(r), dm = dpp_from_lane_below(dl);
                 pp = dpp_from_lane_above(p), rp = dpp_from_lane_above(r), dp = dpp_from_lane_above(dl);
             } else {
