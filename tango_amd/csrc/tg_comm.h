@@ -178,10 +178,16 @@ struct WaveGroup {
         for (int m = LPP >> 1; m > 0; m >>= 1) v = fmax(v, __shfl_xor(v, m, LPP));
         return v;
     }
+    // OR of `pred` over the group; a whole wavefront combines the two flag bits 0 and 1 that the callers use by two
+    // ballots instead of six shuffle steps
     __device__ int any(int pred) const {
+        if constexpr (LPP == 64) {
+            return (__ballot(pred & 1) != 0 ? 1 : 0) | (__ballot(pred & 2) != 0 ? 2 : 0);
+        } else {
 #pragma unroll
-        for (int m = LPP >> 1; m > 0; m >>= 1) pred |= __shfl_xor(pred, m, LPP);
-        return pred;
+            for (int m = LPP >> 1; m > 0; m >>= 1) pred |= __shfl_xor(pred, m, LPP);
+            return pred;
+        }
     }
     // CNT maxima and CNT sums over the group in one go (one pair of barriers for a workgroup-sized group)
     template <int CNT>
