@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the fused Picard iteration on the synthetic ensembles of the benchmark set.
 
-    python bench.py --gpus N --steps K --warmup W [--config metric|c2|c3|c4] [--iters-per-launch k]
+    python bench.py --gpus N --steps K --warmup W [--config metric|c2|c3|c4|c5] [--iters-per-launch k] [--theta convective]
 
 One "step" = one Picard iteration (EWMA -> flux -> split -> EWMA -> assembly -> residual -> solve -> validity
 check) of every profile of the ensemble, all profiles forced active.  Configurations (per GPU):
@@ -9,6 +9,10 @@ check) of every profile of the ensemble, all profiles forced active.  Configurat
   c2      one field, 65 536 x 256
   c3      three fields n, pi<->pe with nonlinear nu, 16 384 x 512, EWMA 0.3/0.3, dt = 1e6
   c4      one field, 4 096 x 8192, EWMA 0.3/0.3 (segmented form of the step)
+  c5      one field, 131 072 x 512 per GPU: with --gpus 8 the 1 048 576-profile ensemble (rank r holds the r-th eighth)
+--theta convective replaces the example's thetaParams (Dmax = 1e13: the whole flux is diffusive, c = 0) by Dmin = 0.1,
+Dmax = 10, dpdxThreshold = 1, with which part of the flux of most profiles is convective (c != 0): the upwinding
+weights and the EWMA of c then work on numbers, not on zeros.
 --iters-per-launch k (one-field configurations up to 2048 points; default 64 for metric and c2) runs k consecutive
 steps in one kernel launch with every profile held in registers in between: the arithmetic, the per-iteration
 convergence test and the residual history are those of k single launches, only the HBM round trip of the state
@@ -20,8 +24,9 @@ N > 1: one process per GPU.  Started by a launcher (RANK / WORLD_SIZE in the env
 torch.distributed.run) every process is one rank; started plainly with --gpus N this process starts the N ranks
 itself, before it touches any GPU, and relays rank 0's line.  The ensemble shards with no data exchange
 (weak scaling: every GPU holds a full-size shard); the only collectives are the all-reduces of the convergence
-counters and of the residual summary (RCCL), issued every --check-every steps inside the timed region; their
-result, read one check later so that the host never waits for the GPU, decides whether the loop goes on.
+counters and of the residual summary (RCCL), issued every --check-every steps inside the timed region (and once at
+its end when it is shorter than that: a timed region never goes without a check); their result, read one check later so
+that the host never waits for the GPU, decides whether the loop goes on.
 
 Rank 0 prints ONE JSON line.  `value` is in "Picard iterations per second of a full-size ensemble": (profiles on
 all GPUs / profiles per GPU of the configuration) x steps / time.
@@ -49,7 +54,10 @@ CONFIGS = {
     'c2':     (1,      65536,    256,  1.0,    1e4,  72,          64),
     'c3':     (3,      16384,    512,  0.3,    1e6,  216,         1),
     'c4':     (1,      4096,     8192, 0.3,    1e4,  72,          16),
+    'c5':     (1,      131072,   512,  1.0,    1e4,  72,          64),
 }
+THETAS = {'example': dict(Dmin=1e-5, Dmax=1e13, dpdxThreshold=10.0), 'convective': dict(Dmin=0.1, Dmax=10.0, dpdxThreshold=1.0)}
+K1_MIN_LAUNCHES = 100            # launches of the single-iteration leg, whatever --steps
 METRIC = 'Picard iters/sec, 64K-profile Shestakov ensemble N=512 fp64; % of HBM peak'
 
 
@@ -82,15 +90,38 @@ def spawn_ranks(n):
     return 0
 
 
-def cpu_baseline_1f(nprof, n, a_prof, seconds):
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_threads():
+    """The cores this process may use: the share the scheduler of the machine gave it (OMP_NUM_THREADS when the
+    environment sets it, as a box that hands out a slice of a larger host does; else the affinity mask).  os.cpu_count()
+    is the whole host, which on a shared machine is not ours to fill."""
+    env = os.environ.get('OMP_NUM_THREADS', '')
+    if env.isdigit() and int(env) > 0:
+        return int(env), 'OMP_NUM_THREADS'
+    try:
+        return len(os.sched_getaffinity(0)), 'affinity mask'
+    except AttributeError:
+        return os.cpu_count() or 1, 'os.cpu_count()'
+
+
+def cpu_baseline_1f(nprof, n, a_prof, seconds, theta):
     """The CPU restatement of the same iteration (oracle/tango_oracle.c, OpenMP over profiles) on a subsample of the
     same ensemble, timed on this host.  Checker code used as a reported baseline only."""
     from oracle import c_oracle
     from tango_amd.ensemble import shestakov_ensemble
     sub = max(16, min(nprof, (4096 * 512) // n))
     ens = shestakov_ensemble(nprof, n, lo=0, hi=sub)
-    threads = min(16, os.cpu_count() or 1)
-    E = c_oracle.Ensemble1F(ens, a_prof=a_prof, fixed_count=True, max_iter=1)
+    threads, threads_from = cpu_threads()
+    E = c_oracle.Ensemble1F(ens, a_prof=a_prof, fixed_count=True, max_iter=1, Dmin=theta['Dmin'], Dmax=theta['Dmax'], thr=theta['dpdxThreshold'])
     used = E.step(threads)                       # warm-up, also reports the thread count
     t0 = time.perf_counter()
     steps = 0
@@ -104,10 +135,11 @@ def cpu_baseline_1f(nprof, n, a_prof, seconds):
     return {'value': rate, 'unit': f'iters/s ({nprof}-profile ensemble equivalents)', 'cores': int(used), 'kind': 'port',
             'sample': f'{steps} iterations of the first {sub} of the {nprof} profiles, N={n}, {el:.1f} s wall, '
                       f'C restatement of the reference path (oracle/tango_oracle.c), OpenMP {used} threads',
-            'profile_iterations_per_s': steps * sub / el, 'faithful_numpy': cpu_faithful_1f(nprof, n, a_prof)}
+            'cpu_model': cpu_model(), 'host_cpus_visible': os.cpu_count(), 'threads_from': threads_from,
+            'profile_iterations_per_s': steps * sub / el, 'faithful_numpy': cpu_faithful_1f(nprof, n, a_prof, theta)}
 
 
-def cpu_faithful_1f(nprof, n, a_prof, seconds=3.0):
+def cpu_faithful_1f(nprof, n, a_prof, theta, seconds=3.0):
     """The reference's own shape of the computation: one profile at a time on one core, NumPy expressions and
     SciPy's banded solver (oracle/tango_oracle.py), for a few seconds on member 0 of the ensemble."""
     from oracle import tango_oracle as orc
@@ -119,7 +151,7 @@ def cpu_faithful_1f(nprof, n, a_prof, seconds=3.0):
     t0 = time.perf_counter()
     steps = 0
     while time.perf_counter() - t0 < seconds:
-        orc.picard_step_1f(st, 1e4, ens['dx'], ens['nL'][0], H1, H7, 0.3, a_prof)
+        orc.picard_step_1f(st, 1e4, ens['dx'], ens['nL'][0], H1, H7, 0.3, a_prof, theta)
         steps += 1
     el = time.perf_counter() - t0
     return {'profile_iterations_per_s': steps / el, 'cores': 1,
@@ -162,8 +194,13 @@ def main():
     ap.add_argument('--iters-per-launch', type=int, default=0,
                     help='Picard iterations per kernel launch (profiles stay in registers in between); 0 = the configuration\'s default')
     ap.add_argument('--check-every', type=int, default=64, help='steps between convergence all-reduces')
+    ap.add_argument('--theta', choices=sorted(THETAS), default='example',
+                    help='thetaParams of the flux split: the example\'s (c = 0 everywhere) or a set that makes part of the flux convective')
     ap.add_argument('--clock-warmup-ms', type=float, default=50.0,
                     help='untimed launches before the warm-up steps, until the GPU has been busy this long (0: none)')
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
+                    help='torch.distributed backend of the all-reduces: nccl (= RCCL, one GPU per rank) or gloo (a rehearsal of the '
+                         'multi-rank path on fewer GPUs than ranks: rank r uses GPU r modulo the visible ones)')
     ap.add_argument('--profiles-per-gpu', type=int, default=0)
     ap.add_argument('--n', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -182,13 +219,15 @@ def main():
     from tango_amd import distributed as D
     from tango_amd.ensemble import OneFieldEnsemble, ThreeFieldEnsemble, shard_range, shestakov_ensemble, threefield_ensemble
 
-    rank, world, local = D.init_from_env()
+    rank, world, local = D.init_from_env(backend=args.backend if torch.cuda.is_available() else 'gloo')
     if world != args.gpus:
         if rank == 0:
             print(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks', file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    if args.backend == 'gloo' and world > 1:
+        local %= torch.cuda.device_count()
     if torch.cuda.device_count() <= local:
         raise SystemExit(f'bench.py: rank {rank} needs GPU {local} but {torch.cuda.device_count()} are visible')
     torch.cuda.set_device(local)
@@ -203,14 +242,17 @@ def main():
     if fields == 3:
         kper = 1                                   # the three-field kernel runs one iteration per launch
     check = max(kper, args.check_every - args.check_every % kper)
-    k1_steps = max(8, args.steps // 4) if kper > 1 else 0
+    k1_steps = max(K1_MIN_LAUNCHES, args.steps // 4) if kper > 1 else 0
+    theta = THETAS[args.theta]
+    if fields == 3 and args.theta != 'example':
+        raise SystemExit('bench.py: --theta applies to the one-field configurations')
     rows = args.warmup + args.steps + k1_steps + 8  # residual history columns: every iteration of this run
     nb_total = per_gpu * world
     lo, hi = shard_range(nb_total, rank, world)
     alloc = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=dev)     # torch owns the state pool
     if fields == 1:
         ens = shestakov_ensemble(nb_total, n, lo=lo, hi=hi)
-        E = OneFieldEnsemble(ens, dt=dt, a_turb=0.3, a_prof=a_prof, tol=1e-11, fixed_count=True, keep_err=True, max_iter=rows, alloc=alloc)
+        E = OneFieldEnsemble(ens, dt=dt, a_turb=0.3, a_prof=a_prof, tol=1e-11, theta=theta, fixed_count=True, keep_err=True, max_iter=rows, alloc=alloc)
     else:
         ens = threefield_ensemble(nb_total, n, lo=lo, hi=hi)
         E = ThreeFieldEnsemble(ens, dt=dt, a_turb=0.3, a_prof=a_prof, tol=1e-9, fixed_count=True, keep_err=True, max_iter=rows, alloc=alloc)
@@ -224,8 +266,11 @@ def main():
 
     def run(nsteps):
         """Up to nsteps Picard iterations: launches of kper iterations (a shorter one at the end if needed), a
-        convergence check every `check` steps; the loop ends early when a check found nothing left to iterate."""
+        convergence check every `check` steps; the loop ends early when a check found nothing left to iterate.  A run
+        shorter than the check interval still ends with one check (device reductions + all-reduces + copy), so that
+        no timed region, however few its steps, goes without the collective."""
         done = 0
+        issued = mon.issued
         while done < nsteps:
             k = min(kper, nsteps - done)
             E.step(stream.cuda_stream, iters=k)
@@ -234,11 +279,21 @@ def main():
                 if nothing_left():
                     break
                 mon.issue()
+        if mon.issued == issued and nsteps > 0:
+            nothing_left()
+            mon.issue()
         return done
 
-    def fence():
+    def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local])
+            if args.backend == 'nccl':
+                dist.barrier(device_ids=[local])
+            else:
+                torch.cuda.synchronize()
+                dist.barrier()
+
+    def fence():
+        barrier()
         torch.cuda.synchronize()
 
     run(args.warmup)
@@ -248,24 +303,22 @@ def main():
     # same 20-iteration launch (22 403 vector instructions per wavefront either way, counted with rocprofv3) takes 4.0 ms
     # after 5 warm-up steps, 3.5 ms after 128 and 3.25 ms after 256 or more.  The requested warm-up can be that short
     # (5 steps = 1 ms), so the clock is brought up by further untimed launches right before the timed region; they are
-    # neither warm-up steps nor timed steps, are reported as clock_warmup_iterations, and leave the iteration counters
-    # (the columns of the residual history) where the warm-up steps left them.
+    # neither warm-up steps nor timed steps, are reported as clock_warmup_iterations, and leave nothing behind: the whole
+    # state pool (profiles, EWMA memories, status, iteration counters, residual history) is copied aside before them and put
+    # back afterwards, so the timed steps are iterations warmup .. warmup+steps-1 of the ensemble's own trajectory.
     clock_warmup = 0
     if args.clock_warmup_ms > 0:
-        if world > 1:
-            dist.barrier(device_ids=[local])     # start together, so that the ranks also reach the timed region's barrier together
-        saved = torch.empty(E.iters.nbytes, dtype=torch.uint8, device=dev)
-        H.check(H.lib.tg_copy_d2d(saved.data_ptr(), E.iters.ptr, E.iters.nbytes, stream.cuda_stream))
+        barrier()                                # start together, so that the ranks also reach the timed region's barrier together
+        saved = torch.empty(E.pool.nbytes, dtype=torch.uint8, device=dev)
+        H.check(H.lib.tg_copy_d2d(saved.data_ptr(), E.pool.ptr, E.pool.nbytes, stream.cuda_stream))
         t_up = time.perf_counter()
         while (time.perf_counter() - t_up) * 1e3 < args.clock_warmup_ms:
             for _ in range(4):
                 E.step(stream.cuda_stream, iters=kper)
                 clock_warmup += kper
             torch.cuda.synchronize()
-        for _ in range(2):
-            E.step(stream.cuda_stream, iters=kper)
-            clock_warmup += kper
-        H.check(H.lib.tg_copy_d2d(E.iters.ptr, saved.data_ptr(), E.iters.nbytes, stream.cuda_stream))
+        H.check(H.lib.tg_copy_d2d(E.pool.ptr, saved.data_ptr(), E.pool.nbytes, stream.cuda_stream))
+        del saved
     fence()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     issued_before = mon.issued
@@ -358,7 +411,9 @@ def main():
                       'kernel_ms': k1_max, 'iters_per_s': (nb_total / per_gpu) * 1e3 / k1_max, 'steps': k1_steps,
                       'algorithmic_bytes_per_launch': bytes_per_iter,
                       'note': 'the same step, one Picard iteration per launch: the state crosses HBM every iteration (72 B/point)'}
-        what = {1: f'one-field Shestakov ensemble, {per_gpu} profiles x N={n} per GPU, EWMA 0.3/{a_prof}, dt={dt:g}, fused assemble+solve',
+        what = {1: f'one-field Shestakov ensemble, {per_gpu} profiles x N={n} per GPU'
+                   + (f' ({nb_total} profiles in all: rank r holds the r-th contiguous range)' if world > 1 else '')
+                   + f', EWMA 0.3/{a_prof}, dt={dt:g}, fused assemble+solve',
                 3: f'three-field (n, pi<->pe, nonlinear nu) ensemble, {per_gpu} profiles x N={n} per GPU, EWMA 0.3/{a_prof}, dt={dt:g}, '
                    f'fused assemble + scalar and 2x2 block solves'}[fields]
         out = {
@@ -370,27 +425,30 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': what + ', all profiles active, seeds as in tango_amd.ensemble',
-                       'name': args.config, 'profiles_total': nb_total, 'grid_points': n,
+                       'name': args.config, 'profiles_total': nb_total, 'grid_points': n, 'theta_params': dict(theta, name=args.theta),
+                       'world_size': dist.get_world_size() if dist.is_initialized() else 1,
+                       'backend': dist.get_backend() if dist.is_initialized() else None,
                        'launch_shape': {'iterations_per_launch': kper, 'launches_in_timed_region': launches,
                                         'iterations_in_last_launch': args.steps - (launches - 1) * kper,
                                         'clock_warmup_iterations': clock_warmup,
                                         'check_every': check, 'all_reduce_rounds_in_timed_region': timed_checks,
                                         'reduced_results_consumed': mon.consumed},
-                       'parallelism': f'batch sharded over {world} GPU(s); RCCL all-reduce of 4 int64 counters + 5 fp64 residual '
-                                      f'summary values per check' if world > 1 else 'one GPU (no collective traffic)'},
+                       'parallelism': f'batch sharded over {world} GPU(s), contiguous ranges, no data exchange; RCCL all-reduce of 4 int64 '
+                                      f'counters + 5 fp64 residual summary values per check' if world > 1 else 'one GPU (no collective traffic)'},
             'roofline': roofline,
             'convergence_summary_last_check': {k: (float(v) if v is not None else None) for k, v in red.items()},
             'invalid_profiles': bad,
         }
         if hbm_k1:
-            out['hbm_roofline_single_iteration_launch'] = hbm_k1
+            # the metric's "% of HBM peak": the same step with one iteration per launch, timed in this run
+            roofline['hbm'] = hbm_k1
         out['hbm_frac_headline'] = roofline['frac'] if roofline['bound'] == 'hbm' else hbm_k1['frac']
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_3f(per_gpu, n, args.cpu_seconds) if fields == 3 else \
-                cpu_baseline_1f(per_gpu, n, a_prof, args.cpu_seconds)
+                cpu_baseline_1f(per_gpu, n, a_prof, args.cpu_seconds, theta)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local])
+        barrier()
         dist.destroy_process_group()
 
 

@@ -290,7 +290,10 @@ int tg_picard_1f_step(const tg_state_1f *state, const tg_params_1f *params, tg_s
  * until the process ends.  tg_picard_1f_work_bytes(nb, n) (with pseudo_time: tg_picard_1f_work_bytes_tread) must not exceed
  * TG_STATIC_WORK_BYTES (about 4.7 million
  * grid points in all, e.g. 512 x 8192); larger ensembles get TG_ERR_ARG, other profile lengths TG_ERR_UNSUPPORTED
- * (they need no work space: tg_picard_1f_step allocates nothing for them either).  The call allocates and frees
+ * (they need no work space: tg_picard_1f_step allocates nothing for them either).  A call with n = 4096 and
+ * iters_per_launch > 1 goes where tg_picard_1f_step sends it, to the workgroup kernel that keeps the profile in registers
+ * and uses no work space.  The stream must belong to the device that is current (TG_ERR_ARG otherwise: every GPU has its
+ * own copy of the array).  The call allocates and frees
  * nothing; the first call on a device looks up the array's address (make it outside graph capture).  All calls
  * on one GPU share that array: calls that overlap in time on one GPU (different streams or threads) race; calls
  * ordered on one stream are safe, every call clears what it needs cleared.  With tread_lightly the call waits for the

@@ -8,7 +8,7 @@ for rep in 1 2 3; do
     python - "$lib" <<'PY'
 import json, sys
 d = json.load(open('/tmp/ab.json'))
-k1 = d.get('hbm_roofline_single_iteration_launch', {}).get('kernel_ms')
+k1 = d['roofline'].get('hbm', {}).get('kernel_ms')
 print(f"{sys.argv[1]:45s} value {d['value']:.1f}  ms/step {d['ms_per_step']:.4f}  k1_ms {k1}")
 PY
   done

@@ -2,7 +2,7 @@ run() { echo "== $*"; timeout -k 10 200 python bench.py --no-cpu-baseline "$@" 2
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); r=d['roofline']; k1=d.get('hbm_roofline_single_iteration_launch',{})
+        d=json.loads(l); r=d['roofline']; k1=r.get('hbm',{})
         print('ms/step %.4f value %.1f bound %s frac %s k1_ms %s k1_frac %s issue %s'%(d['ms_per_step'],d['value'],r['bound'],r['frac'],k1.get('kernel_ms'),k1.get('frac'),r.get('valu_issue_frac')))
 " || exit 1; }
 run --steps 256 --warmup 64

@@ -76,7 +76,7 @@ pair_solve_kernel(PairArgs a, int64_t nb, int n, int32_t *__restrict__ status) {
     store_chunk<P, false>(a.U + off, n, j0, xu);
     store_chunk<P, false>(a.W + off, n, j0, xw);
     if (status) {
-        const int sing = g.any(el.singular);
+        const int sing = g.any2(el.singular);
         if (sing && g.t() == 0) atomicOr(&status[b], TG_ST_SINGULAR);
     }
 }
@@ -123,7 +123,7 @@ block3_solve_kernel(const double *__restrict__ Cb, const double *__restrict__ Bb
             for (int r = 0; r < 3; ++r) x[r * plane + off + j0 + i] = xs[i].v[r];
         }
     if (status) {
-        const int sing = g.any(el.singular);
+        const int sing = g.any2(el.singular);
         if (sing && g.t() == 0) atomicOr(&status[b], TG_ST_SINGULAR);
     }
 }
@@ -522,7 +522,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             far |= in && (fabs((tp[i].v[0] - u[1][i + 1]) / u[1][i + 1]) >= Q.tread_max_change);
             far |= in && (fabs((tp[i].v[1] - u[2][i + 1]) / u[2][i + 1]) >= Q.tread_max_change);
         }
-        far = g.any(far);
+        far = g.any2(far);
         if (!settled && far && attempt >= TG_TREAD_MAX_HALVINGS) tread_limit = true;
         settled = settled || !far || attempt >= TG_TREAD_MAX_HALVINGS;
         if (G::kBlock ? settled : !__any(!settled)) break;
@@ -547,7 +547,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         store_chunk<P, false>(S_.u[1] + off, n, j0, xi);
         store_chunk<P, false>(S_.u[2] + off, n, j0, xe);
     }
-    bad = g.any(bad | (singular << 1));
+    bad = g.any2(bad | (singular << 1));
     if (t == 0) {
         int ns = st;
         if (!Q.frozen_turb) {

@@ -109,7 +109,7 @@ tridiag_pf_kernel(const double *__restrict__ A, const double *__restrict__ B, co
         store_chunk<P, FULL>(u + off, n, j0, d);
     }
     if (status) {
-        sing = g.any(sing);
+        sing = g.any2(sing);
         if (sing && g.t() == 0) atomicOr(&status[b], TG_ST_SINGULAR);
     }
 }
@@ -1360,7 +1360,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                 const double change = (xt[i] - u[i + 1]) / u[i + 1];
                 far |= (j0 + i < Q.tread_inner_count) && (fabs(change) >= Q.tread_max_change);
             }
-            far = g.any(far);
+            far = g.any2(far);
             if (!settled && far && attempt >= TG_TREAD_MAX_HALVINGS) tread_limit = true;
             settled = settled || !far || attempt >= TG_TREAD_MAX_HALVINGS;
             if (G::kBlock ? settled : !__any(!settled)) break;
@@ -1374,7 +1374,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             bad |= (FULL || j0 + i < n) ? !(isfinite(x[i]) && x[i] >= 0.0) : 0;
             u[i + 1] = hold ? u[i + 1] : x[i];
         }
-        bad = g.any(bad | (singular << 1));
+        bad = g.any2(bad | (singular << 1));
 
         if (!done) {
             if (t == 0 && S_.err && it0 < S_.err_stride) S_.err[b * S_.err_stride + it0] = rms;

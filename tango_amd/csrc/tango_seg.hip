@@ -443,7 +443,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         int bad = 0;
 #pragma unroll
         for (int i = 0; i < P; ++i) bad |= !(isfinite(x[i]) && x[i] >= 0.0);
-        bad = g.any(bad);
+        bad = g.any2(bad);
         wt.put(0, x);
         Tile::sync();
         wt.flush(0, S_.u + woff);
@@ -591,7 +591,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         (W.row[3] + lane_base)[lane_off] = own ? r7 : r7 - e7 * T0;
         mx = g.max(mx);
         ss = g.sum(ss);
-        const int sing = g.any(el.singular);
+        const int sing = g.any2(el.singular);
         if (t == 0) {
             double *Fq = W.first + 3 * (b * S + s);
             Fq[0] = F;
@@ -718,7 +718,7 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next, in
     el.finish(g, y);
 #pragma unroll
     for (int i = 0; i < P; ++i) W.y[lane_slot(b, n, t * P + i)] = y[i];
-    const int sing = g.any(el.singular);
+    const int sing = g.any2(el.singular);
     if (next) {
         // another iteration follows in this call: the boundary copies of the memories (as the first halves have just
         // left them) and the new profile next to every boundary, for the kernel that does the second half of this
@@ -872,10 +872,19 @@ constexpr int kMaxDevices = 64;
 void *scratch_ptr[kMaxDevices] = {};      // device address of `scratch` on each device, resolved on first use
 std::mutex scratch_mutex;
 
-int scratch_on_current_device(void **out) {
+// The array of the device that is current; `stream` must belong to that device (a launch on another device's stream
+// would hand that device this device's address).
+int scratch_on_current_device(void **out, hipStream_t stream) {
     int dev = -1;
     TG_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= kMaxDevices) return fail(TG_ERR_UNSUPPORTED, "device ordinal beyond the library's table%s");
+    if (stream) {
+        hipDevice_t sdev = -1;
+        TG_HIP(hipStreamGetDevice(stream, &sdev));
+        if ((int)sdev != dev)
+            return fail(TG_ERR_ARG, "tg_picard_1f_step_static: the stream belongs to another device than the current one "
+                                    "(make the stream's device current before the call)%s");
+    }
     std::lock_guard<std::mutex> lock(scratch_mutex);
     if (!scratch_ptr[dev]) {
         void *p = nullptr;
@@ -898,12 +907,20 @@ extern "C" int tg_picard_1f_step_static(const tg_state_1f *st, const tg_params_1
                                 "(about 4.7 million grid points in all, e.g. 512 profiles of 8192 points)%s");
     if (st->nb == 0) return TG_OK;
     void *ws = nullptr;
-    if (int e = scratch_on_current_device(&ws)) return e;
+    if (int e = scratch_on_current_device(&ws, S(stream))) return e;
     tg_params_1f p = *q;
     p.work = ws;
     p.work_bytes = TG_STATIC_WORK_BYTES;
-    if (!tg_seg_applies(st, &p))
-        return fail(TG_ERR_UNSUPPORTED, "tg_picard_1f_step_static: the segmented step needs the built-in flux, Cartesian geometry, one "
-                                        "no iterate history and 16-byte aligned arrays%s");
-    return tg_seg_step(st, &p, S(stream));
+    if (tg_seg_applies(st, &p)) return tg_seg_step(st, &p, S(stream));
+    // 4096 points with several iterations per call: tg_picard_1f_step itself prefers the workgroup kernel there (the
+    // profile stays in registers between the iterations), which uses no work space at all, so nothing is allocated either
+    tg_params_1f one = p;
+    one.iters_per_launch = 1;
+    if (st->n == 4096 && q->iters_per_launch > 1 && tg_seg_applies(st, &one)) {
+        p.work = nullptr;
+        p.work_bytes = 0;
+        return tg_picard_1f_dispatch(st, &p, S(stream));
+    }
+    return fail(TG_ERR_UNSUPPORTED, "tg_picard_1f_step_static: the segmented step needs the built-in flux, Cartesian geometry, no flux "
+                                    "smoothing or multiplier, no iterate history and 16-byte aligned arrays%s");
 }

@@ -52,8 +52,15 @@ __device__ __forceinline__ double quot(double n, double d) {
 
 // n / d for a divisor whose correctly rounded reciprocal `inv` = 1/d is at hand (a launch constant, formed once by a
 // true division): the product and one residual correction, the last two steps of the division sequence above with the
-// exact reciprocal in place of the refined estimate, 3 issue slots instead of 8.  Correctly rounded under the same
-// conditions (normal operands far from the exponent limits).
+// exact reciprocal in place of the refined estimate, 3 issue slots instead of 8.  The product q is within 1.5 ulp of
+// n/d (half an ulp of inv, half an ulp of the product), the residual n - d q is exact or rounded in its 54th bit, and
+// the result is the correct rounding of n/d + delta with |delta| of a few 2^-53 ulp: the correctly rounded quotient
+// unless n/d lies that close to the midpoint of two doubles (the nearest a quotient of two doubles can come to one is
+// 2^-54 ulp).  No such operand pair
+// turned up among 300 000 random and hard-to-round ones (mantissas of all ones, next to a power of two) run through this
+// sequence in exact rational arithmetic (tests/test_host_logic.py::test_short_quotient_rounds_like_a_division), and the
+// theta golden vectors, whose values depend on this rounding to the bit, reproduce.  Normal operands far from the
+// exponent limits only.
 __device__ __forceinline__ double quot_by(double n, double d, double inv) {
     const double q = n * inv;
     return __builtin_fma(__builtin_fma(-d, q, n), inv, q);
@@ -178,9 +185,11 @@ struct WaveGroup {
         for (int m = LPP >> 1; m > 0; m >>= 1) v = fmax(v, __shfl_xor(v, m, LPP));
         return v;
     }
-    // OR of `pred` over the group; a whole wavefront combines the two flag bits 0 and 1 that the callers use by two
-    // ballots instead of six shuffle steps
-    __device__ int any(int pred) const {
+    // OR over the group of the two flag bits 0 and 1 of `pred` (what the callers pass: invalid | singular << 1 and the
+    // like); the other bits are dropped in every group shape.  A whole wavefront combines the two bits by two ballots
+    // instead of six shuffle steps.
+    __device__ int any2(int pred) const {
+        pred &= 3;
         if constexpr (LPP == 64) {
             return (__ballot(pred & 1) != 0 ? 1 : 0) | (__ballot(pred & 2) != 0 ? 2 : 0);
         } else {
@@ -331,9 +340,9 @@ struct BlockGroup {
         __syncthreads();
         return tot;
     }
-    // OR of the two flag bits 0 and 1 of `pred` over the workgroup.  (Not __syncthreads_or: that one reads the
-    // workgroup's size from memory, and a wait for that load also waits for every store the wavefront has issued.)
-    __device__ int any(int pred) const {
+    // OR of the two flag bits 0 and 1 of `pred` over the workgroup, the other bits dropped.  (Not __syncthreads_or: that
+    // one reads the workgroup's size from memory, and a wait for that load also waits for every store the wavefront has issued.)
+    __device__ int any2(int pred) const {
         const int mine = (__ballot(pred & 1) != 0 ? 1 : 0) | (__ballot(pred & 2) != 0 ? 2 : 0);
         int *flags = reinterpret_cast<int *>(lds_);
         if ((t_ & 63) == 0) flags[t_ >> 6] = mine;

@@ -61,7 +61,10 @@ class ConvergenceMonitor:
     work behind it (by then the copy has landed long ago), as a dict, or None when no check is outstanding.  Every
     rank sees the same reduced numbers, so every rank takes the same decision on the same check.
 
-    `ensemble` provides reduce_status(stream, counts_ptr) and reduce_residual(out_ptr, stream)."""
+    `ensemble` provides reduce_status(stream, counts_ptr) and reduce_residual(out_ptr, stream).  `stream` is a
+    torch.cuda.Stream, the one the ensemble's steps are launched on; everything issue() queues (the library's
+    reductions, torch's all-reduces, conversions and copies) goes to that stream, whatever torch's current stream is
+    when it is called."""
 
     def __init__(self, ensemble, device, stream):
         import torch
@@ -75,13 +78,14 @@ class ConvergenceMonitor:
 
     def issue(self):
         import torch
-        self.E.reduce_status(self.stream.cuda_stream, self.counts.data_ptr())
-        self.E.reduce_residual(self.summary.data_ptr(), self.stream.cuda_stream)
-        allreduce_counts(self.counts)
-        allreduce_residual(self.summary)
-        self.host[:4].copy_(self.counts.to(torch.float64), non_blocking=True)
-        self.host[4:].copy_(self.summary, non_blocking=True)
-        self.landed.record(self.stream)
+        with torch.cuda.stream(self.stream):     # torch's collectives and copies follow its current stream
+            self.E.reduce_status(self.stream.cuda_stream, self.counts.data_ptr())
+            self.E.reduce_residual(self.summary.data_ptr(), self.stream.cuda_stream)
+            allreduce_counts(self.counts)
+            allreduce_residual(self.summary)
+            self.host[:4].copy_(self.counts.to(torch.float64), non_blocking=True)
+            self.host[4:].copy_(self.summary, non_blocking=True)
+            self.landed.record(self.stream)
         self.pending = True
         self.issued += 1
 

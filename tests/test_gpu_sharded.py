@@ -180,7 +180,8 @@ def test_two_ranks_on_two_gpus_over_rccl(tmp_path):
 
 
 @pytest.mark.parametrize('extra', [['--iters-per-launch', '8'], ['--iters-per-launch', '1'], ['--config', 'c4', '--profiles-per-gpu', '64'],
-                                   ['--config', 'c3', '--profiles-per-gpu', '512']])
+                                   ['--config', 'c3', '--profiles-per-gpu', '512'], ['--iters-per-launch', '64', '--check-every', '64'],
+                                   ['--config', 'c5', '--iters-per-launch', '8', '--theta', 'convective']])
 def test_bench_line(extra):
     """bench.py end to end on one GPU at a reduced ensemble size: one JSON line whose launch shape is the one that ran
     and whose roofline fractions are fractions."""
@@ -197,13 +198,39 @@ def test_bench_line(extra):
     assert out['n_gpus'] == 1 and out['steps'] == 24 and out['value'] > 0 and out['invalid_profiles'] == 0
     shape = out['config']['launch_shape']
     k = shape['iterations_per_launch']
-    assert shape['launches_in_timed_region'] == -(-24 // k) and shape['all_reduce_rounds_in_timed_region'] == 24 // shape['check_every']
+    assert shape['launches_in_timed_region'] == -(-24 // k) and shape['all_reduce_rounds_in_timed_region'] == max(1, 24 // shape['check_every'])
     roof = out['roofline']
     # one iteration per launch crosses HBM every iteration, and so does the segmented form's chain of kernels (c4); only the
     # register-resident multi-iteration kernel is bound by fp64 issue
     assert roof['bound'] == ('hbm' if (k == 1 or 'c4' in extra) else 'valu_fp64')
     if 'c4' in extra:
-        assert k == 16 and roof['iterations_per_launch'] == 12 and 'hbm_roofline_single_iteration_launch' in out
+        assert k == 16 and roof['iterations_per_launch'] == 12 and 'hbm' in roof
     assert roof['frac'] is None or 0 < roof['frac'] <= 1
     assert 0 < out['hbm_frac_headline'] <= 1
+    if k > 1:
+        assert roof['hbm']['bound'] == 'hbm' and roof['hbm']['steps'] >= 100 
+        assert out['hbm_frac_headline'] == (roof['frac'] if roof['bound'] == 'hbm' else roof['hbm']['frac'])
+    assert out['config']['world_size'] == 1 and out['config']['theta_params']['name'] == ('convective' if '--theta' in extra else 'example')
     assert out['convergence_summary_last_check']['active'] == out['config']['profiles_total']
+
+
+def test_bench_two_ranks_share_the_gpu():
+    """bench.py --gpus 2 --backend gloo: the multi-rank path of the benchmark (rank processes started by bench.py itself,
+    contiguous shards of the two-shard ensemble, barriers, all-reduces inside the timed region, maximum over the ranks)
+    rehearsed with both ranks on this box's one GPU.  With the driver's own arguments (20 steps, 64 iterations per
+    launch) the timed region still holds one all-reduce round."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5', '--backend', 'gloo',
+           '--config', 'c5', '--profiles-per-gpu', '4096', '--clock-warmup-ms', '5']
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    cfg = out['config']
+    assert out['n_gpus'] == 2 and cfg['world_size'] == 2 and cfg['backend'] == 'gloo' and cfg['profiles_total'] == 8192
+    assert cfg['launch_shape']['all_reduce_rounds_in_timed_region'] == 1
+    assert out['convergence_summary_last_check']['active'] == 8192 and out['invalid_profiles'] == 0
+    assert 'cpu_baseline' not in out and out['value'] > 0

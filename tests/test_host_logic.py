@@ -239,3 +239,37 @@ def test_ewma_memory_handed_over_as_a_callable_is_fetched_once():
     assert np.array_equal(e._yEWMA_lminus1, [5.0]) and len(calls) == 1
     e.reset_ewma_iterate()
     assert e._yEWMA_lminus1 is None
+
+
+def test_short_quotient_rounds_like_a_division():
+    """The kernels divide by launch constants (dt, dx, dx^2, theta's span Dmax - Dmin) as q = n * inv, q + (n - d q) * inv
+    with inv the correctly rounded 1/d and both corrections fused (quot_by in csrc/tg_comm.h).  theta must round exactly
+    as the reference's division does (1 - theta cancels down to 1e-14), so the sequence is run here in exact rational
+    arithmetic (Fraction -> float rounds correctly, which makes every step the IEEE operation it stands for) on random
+    operand pairs and on mantissas that are hard to round, and compared with the division bit for bit."""
+    import math
+    import random
+    from fractions import Fraction as F
+    rnd = random.Random(7)
+
+    def mantissa(kind):
+        if kind == 1:
+            m = (1 << 52) - 1 - rnd.getrandbits(rnd.randint(0, 20))      # all ones, a few low bits cleared
+        elif kind == 2:
+            m = rnd.getrandbits(rnd.randint(0, 20))                       # next to a power of two
+        else:
+            m = rnd.getrandbits(52) | (kind == 3)
+        return (1 << 52) | m
+
+    beyond_one_ulp = 0
+    for _ in range(20000):
+        n = math.ldexp(mantissa(rnd.randint(0, 3)), rnd.randint(-80, 80) - 52)
+        d = math.ldexp(mantissa(rnd.randint(0, 3)), rnd.randint(-80, 80) - 52)
+        inv = float(F(1) / F(d))
+        q = float(F(n) * F(inv))
+        r = float(F(n) - F(d) * F(q))
+        got = float(F(r) * F(inv) + F(q))
+        want = n / d
+        assert got == want, (n.hex(), d.hex())
+        beyond_one_ulp += abs(F(q) - F(n) / F(d)) > F(math.ulp(want))
+    assert beyond_one_ulp > 0       # the sample does contain first products more than an ulp off: the correction step is what rounds

@@ -9,10 +9,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(nb, n, its, static, tread=False):
+def _run(nb, n, its, static, tread=False, k=1):
     from tango_amd import _hip as H
     from tango_amd.ensemble import OneFieldEnsemble, shestakov_ensemble
-    E = OneFieldEnsemble(shestakov_ensemble(nb, n), a_turb=0.3, a_prof=0.3, tol=1e-9, max_iter=its, segmented=not static, tread=tread)
+    E = OneFieldEnsemble(shestakov_ensemble(nb, n), a_turb=0.3, a_prof=0.3, tol=1e-9, max_iter=its * k, segmented=not static, tread=tread)
     if tread:       # pseudo-timestep control: short first steps, halving of steps that move the profile by 5 % or more
         q = E.params
         q.pseudo_time, q.tread_initial_steps, q.tread_initial_dtau = 1, 1, 0.5
@@ -23,6 +23,7 @@ def _run(nb, n, its, static, tread=False):
         sized = H.lib.tg_picard_1f_work_bytes_tread if tread else H.lib.tg_picard_1f_work_bytes
         assert E.params.work and E.params.work_bytes == sized(nb, n)
     fn = H.lib.tg_picard_1f_step_static if static else H.lib.tg_picard_1f_step
+    E.params.iters_per_launch = k
     for _ in range(its):
         H.check(fn(C.byref(E.state), C.byref(E.params), H.stream()))
     H.synchronize()
@@ -38,6 +39,13 @@ def test_static_work_space_matches_caller_work_space():
         for k in ref:
             assert np.array_equal(got[k], ref[k]), (nb, n, k)
         assert np.all(got['iters'] == its) and np.all(np.isfinite(got['u'])) and not np.any(got['status'] & 6)
+    # several iterations per call: a chain of segment kernels at 8192 points; at 4096 the step prefers the workgroup kernel,
+    # which keeps the profile in registers and needs no work space: the entry point passes such a call on to it
+    for nb, n, its, k in ((9, 8192, 2, 3), (7, 4096, 2, 3)):
+        got, ref = _run(nb, n, its, static=True, k=k), _run(nb, n, its, static=False, k=k)
+        for key in ref:
+            assert np.array_equal(got[key], ref[key]), (nb, n, k, key)
+        assert np.all(got['iters'] == its * k) and not np.any(got['status'] & 6)
     # under pseudo-timestep control the built-in array also holds the previous iterates
     got, ref = _run(6, 4096, 3, static=True, tread=True), _run(6, 4096, 3, static=False, tread=True)
     for k in ref:
