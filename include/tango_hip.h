@@ -352,6 +352,22 @@ typedef struct {
     int32_t tread_initial_steps;
     double tread_max_change;
     double tread_initial_dtau;
+    /* Inputs from outside the kernel: flux_model == TG_FLUX_EXTERNAL replaces the built-in closure by what the reference's
+     * Python objects supply to the same stack.  flux[f]: (nb, n), field f's turbulent flux as fluxModel.get_flux returned
+     * it for the EWMA of the profiles (tango/lodestro_method.py:342-350; the caller advances uE[f] with tg_ewma_profiles
+     * before it evaluates the model, the kernel reads uE and does not write it), split per field as
+     * tango/lodestro_method.py:365-369 does.  H6[f], H7[f], H8[f]: what the fields' compute_all_H callbacks returned
+     * (tango/multifield.py:202, e.g. H6 = -nu, H8 = +nu of examples/shestakov_threefield_nonlinearnu.py:108-149), each
+     * NULL (absent: zero) or an array with stride 0 ((n,), one for all profiles) or n ((nb, n)); H8[0] must be NULL
+     * (field 0 is solved on its own, fields 1 and 2 as a pair: tango/fieldgroups.py:275-331, with H8[1] the coefficient
+     * of field 2's profile in field 1's equation and the other way round, tango/JK_to_matrix_fd.py:97-112).  H1 is 1 and
+     * nu0 is not used.  Not together with pseudo_time.  With frozen_turb (an inner iteration) the fluxes are not read. */
+    int32_t flux_model;
+    int32_t reserved2_;
+    const double *flux[3];
+    const double *H6[3];
+    const double *H8[3];
+    int64_t h6_stride[3], h7_stride[3], h8_stride[3];
 } tg_params_3f;
 
 int tg_picard_3f_step(const tg_state_3f *state, const tg_params_3f *params, tg_stream stream);

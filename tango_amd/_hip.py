@@ -69,7 +69,9 @@ class Params3F(C.Structure):
                 ('dpdx_thr', _dbl), ('tol', _dbl), ('UL', _p * 3), ('H7', _p * 3), ('nu0', _p), ('fixed_count', C.c_int32),
                 ('frozen_turb', C.c_int32), ('outer_count', C.c_int32), ('reserved_', C.c_int32), ('pseudo_time', C.c_int32),
                 ('tread_lightly', C.c_int32), ('tread_inner_count', C.c_int32), ('tread_initial_steps', C.c_int32),
-                ('tread_max_change', _dbl), ('tread_initial_dtau', _dbl)]
+                ('tread_max_change', _dbl), ('tread_initial_dtau', _dbl), ('flux_model', C.c_int32), ('reserved2_', C.c_int32),
+                ('flux', _p * 3), ('H6', _p * 3), ('H8', _p * 3), ('h6_stride', _i64 * 3), ('h7_stride', _i64 * 3),
+                ('h8_stride', _i64 * 3)]
 
 
 # every exported symbol of include/tango_hip.h with its prototype

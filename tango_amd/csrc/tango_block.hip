@@ -142,9 +142,14 @@ constexpr int kExch3f = 18;     // doubles per thread of the workgroup exchange 
 // u_{m-1} slots, the first iterations of a profile may use a short pseudo-timestep, and a step that moves any of the
 // three profiles too far is redone from the previous iterates with dtau = dt/2, dt/4, ... (same turbulent coefficients,
 // same collision frequency) until acceptable.
-template <int P, class G, bool FULL, bool TREAD>
+// EXT: the inputs come from outside the kernel (a flux model and compute_all_H callbacks in Python, or a turbulence code):
+// the three fluxes as arrays evaluated on the EWMA of the profiles, which the caller has advanced (tg_ewma_profiles;
+// tango/lodestro_method.py:342-350), and the callbacks' H6, H7, H8 as arrays (tango/fieldgroups.py:260-273,
+// tango/JK_to_matrix_fd.py:97-112) in place of the built-in flux, sources and collision frequency.
+template <int P, class G, bool FULL, bool TREAD, bool EXT>
 __global__ void __launch_bounds__(G::kBlock ? G::T : 256)
 picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
+    static_assert(!(TREAD && EXT), "pseudo-timestep control is compiled for the built-in closure only");
     extern __shared__ double lds[];
     G g(lds);
     const int64_t b = (int64_t)blockIdx.x * G::profiles_per_block(blockDim.x) + g.profile_in_block();
@@ -179,17 +184,28 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
 
     // Per-profile scalars and the sources of this lane's rows, fetched before anything is stored: a wait for a load also
     // waits for every store issued before it (see `landed`), and the first stores come early in this kernel.
-    const double nu0 = Q.nu0[b];
+    const double nu0 = EXT ? 0.0 : Q.nu0[b];
     double UL[3], h7v[3][P];
+    double h6v[EXT ? 3 : 1][EXT ? P : 1], h8v[EXT ? 2 : 1][EXT ? P : 1];      // H6 of the three fields, H8 of the pair
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         UL[s] = Q.UL[s][b];
 #pragma unroll
-        for (int i = 0; i < P; ++i) h7v[s][i] = Q.H7[s][(FULL || j0 + i < n) ? j0 + i : n - 1];
+        for (int i = 0; i < P; ++i) {
+            const int jc = (FULL || j0 + i < n) ? j0 + i : n - 1;
+            if constexpr (EXT) {
+                h7v[s][i] = Q.H7[s] ? Q.H7[s][b * Q.h7_stride[s] + jc] : 0.0;
+                h6v[s][i] = Q.H6[s] ? Q.H6[s][b * Q.h6_stride[s] + jc] : 0.0;
+                if (s > 0) h8v[s > 0 ? s - 1 : 0][i] = Q.H8[s] ? Q.H8[s][b * Q.h8_stride[s] + jc] : 0.0;
+            } else {
+                h7v[s][i] = Q.H7[s][jc];
+            }
+        }
     }
 
     double u[3][P + 2], DE[3][P], cE[3][P];
     double2 rE[3][KP], rm[3][KP];      // coalesced path: raw uE and u_{m-1} pieces, staged when they are needed
+    double2 rF[EXT ? 3 : 1][KP];       // and the raw pieces of the three outside fluxes
     if constexpr (COOP) {
         double2 ru[3][KP], rD[3][KP], rC[3][KP];
 #pragma unroll
@@ -205,6 +221,12 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         if constexpr (!TREAD) {
 #pragma unroll
             for (int s = 0; s < 3; ++s) wt.fetch(S_.um1[s] + woff, rm[s]);
+        }
+        if constexpr (EXT) {
+            if (turb) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) wt.fetch(Q.flux[s] + woff, rF[s]);
+            }
         }
         wt.stage(0, ru[0]); wt.stage(1, ru[1]); wt.stage(2, ru[2]); wt.stage(3, rD[0]);
         Tile::sync();
@@ -255,23 +277,41 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     for (int s = 0; s < 3; ++s) {
         landed(UL[s]);
 #pragma unroll
-        for (int i = 0; i < P; ++i) landed(h7v[s][i]);
+        for (int i = 0; i < P; ++i) {
+            landed(h7v[s][i]);
+            if constexpr (EXT) {
+                landed(h6v[s][i]);
+                if (s > 0) landed(h8v[s > 0 ? s - 1 : 0][i]);
+            }
+        }
     }
     if (turb) {
         double ue[3][P + 2];
+        double fx[EXT ? 3 : 1][EXT ? P : 1];      // the outside fluxes at this lane's points
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if constexpr (COOP) wt.take(1 + s, ue[s] + 1);
             else load_chunk<P, false>(S_.uE[s] + off, n, j0, ue[s] + 1, 1.0);
+            if constexpr (!EXT) {      // with outside fluxes the caller has advanced the memory: the flux was evaluated on it
 #pragma unroll
-            for (int i = 0; i < P; ++i) ue[s][i + 1] = ewma(Q.a_prof, u[s][i + 1], omp, ue[s][i + 1]);
-            if constexpr (!COOP) store_chunk<P, false>(S_.uE[s] + off, n, j0, ue[s] + 1);
+                for (int i = 0; i < P; ++i) ue[s][i + 1] = ewma(Q.a_prof, u[s][i + 1], omp, ue[s][i + 1]);
+                if constexpr (!COOP) store_chunk<P, false>(S_.uE[s] + off, n, j0, ue[s] + 1);
+            } else if constexpr (!COOP) {
+                load_chunk<P, false>(Q.flux[s] + off, n, j0, fx[s], 0.0);
+            }
         }
-        if constexpr (COOP) {
+        if constexpr (COOP && !EXT) {
             Tile::sync();
             wt.put(1, ue[0] + 1); wt.put(2, ue[1] + 1); wt.put(3, ue[2] + 1);
             Tile::sync();
             wt.flush(1, S_.uE[0] + woff); wt.flush(2, S_.uE[1] + woff); wt.flush(3, S_.uE[2] + woff);
+            Tile::sync();
+        }
+        if constexpr (COOP && EXT) {
+            Tile::sync();
+            wt.stage(1, rF[0]); wt.stage(2, rF[1]); wt.stage(3, rF[2]);
+            Tile::sync();
+            wt.take(1, fx[0]); wt.take(2, fx[1]); wt.take(3, fx[2]);
             Tile::sync();
         }
         {
@@ -297,7 +337,16 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
 #pragma unroll
             for (int s = 0; s < 3; ++s) dd[s] = ddx_edge1_point<EXACT>(ue[s][i], ue[s][i + 1], ue[s][i + 2], first, last, rc);
             const double pi = ue[1][i + 1];
-            if constexpr (EXACT) {
+            if constexpr (EXT) {
+                // tango/lodestro_method.py:365-369: the split of each field's own flux, then the EWMA of D and c
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    double D, c, DH, cH, thv;
+                    flux_split_point<DIV>(fx[s][i], ue[s][i + 1], dd[s], 1.0, 1.0, th, D, c, DH, cH, thv);
+                    DE[s][i] = ewma(Q.a_turb, D, omt, DE[s][i]);
+                    cE[s][i] = ewma(Q.a_turb, c, omt, cE[s][i]);
+                }
+            } else if constexpr (EXACT) {
                 const double Dsh = quot<DIV>(dd[1] * dd[1], pi * pi);     // D = (dpi/dx)^2 / pi^2, shared by the three fluxes
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
@@ -434,8 +483,11 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         const bool valid = FULL || j < n;      // FULL: n = lanes x P, the tests fold away
         const bool last = FULL ? (i == P - 1 && t == G::T - 1) : (j == n - 1);
         // collisional coupling nu = nu0 / ((pi + pe)/n)^{3/2} from the current profiles (example :108-110)
-        const double q = quot<DIV>(u[1][i + 1], u[0][i + 1]) + quot<DIV>(u[2][i + 1], u[0][i + 1]);
-        const double nu = quot<DIV>(nu0, q * sqrt(q));
+        double nu = 0.0;
+        if constexpr (!EXT) {
+            const double q = quot<DIV>(u[1][i + 1], u[0][i + 1]) + quot<DIV>(u[2][i + 1], u[0][i + 1]);
+            nu = quot<DIV>(nu0, q * sqrt(q));
+        }
         double A[3], B[3], C[3], f[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -445,7 +497,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             const double hp3 = (h3c[s] + h3n) / 2.0;
             double bp = 0.5;
             if (weigh) bp = fbeta_point<DIV>(hp2, hp3, rc.dx);
-            const double h6 = (s == 0) ? 0.0 : -nu;       // H6 = -nu for pi and pe (example :125, :144)
+            double h6 = (s == 0) ? 0.0 : -nu;       // H6 = -nu for pi and pe (example :125, :144)
+            if constexpr (EXT) h6 = h6v[s][i];
             fd_row<EXACT>(last, 1.0, TREAD ? u[s][i + 1] : um1[s][TREAD ? 0 : i], rc, UL[s], hm2[s], hm3[s], bm[s], hp2, hp3, bp, 0.0, h6, h7v[s][i], A[s], B[s],
                          C[s], f[s]);
             if (!valid) {
@@ -457,13 +510,19 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             h2c[s] = h2n;
             h3c[s] = h3n;
         }
-        const double Gc = (valid && !last) ? -nu : 0.0;   // G = -H8 = -nu, zero on the Dirichlet row (JK_to_matrix_fd.py:126-129)
+        // G = -H8 (= -nu in the built-in closure), zero on the Dirichlet row (JK_to_matrix_fd.py:126-129); the first field of
+        // the pair carries the coefficient of the second one's profile in its equation and the other way round
+        double Gu = (valid && !last) ? -nu : 0.0, Gw = Gu;
+        if constexpr (EXT) {
+            Gu = (valid && !last) ? -h8v[0][i] : 0.0;
+            Gw = (valid && !last) ? -h8v[1][i] : 0.0;
+        }
         const bool inner = FULL ? !last : (j < n - 1);
         const double up[3] = {inner ? u[0][i + 2] : 0.0, inner ? u[1][i + 2] : 0.0, inner ? u[2][i + 2] : 0.0};
         double r[3];
         r[0] = A[0] * up[0] + B[0] * u[0][i + 1] + C[0] * u[0][i] - f[0];
-        r[1] = A[1] * up[1] + B[1] * u[1][i + 1] + C[1] * u[1][i] + Gc * u[2][i + 1] - f[1];
-        r[2] = A[2] * up[2] + B[2] * u[2][i + 1] + C[2] * u[2][i] + Gc * u[1][i + 1] - f[2];
+        r[1] = A[1] * up[1] + B[1] * u[1][i + 1] + C[1] * u[1][i] + Gu * u[2][i + 1] - f[1];
+        r[2] = A[2] * up[2] + B[2] * u[2][i + 1] + C[2] * u[2][i] + Gw * u[1][i + 1] - f[2];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             ss[s] += valid ? r[s] * r[s] : 0.0;
@@ -477,8 +536,8 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         Am.m[0][0] = A[1];
         Am.m[1][1] = A[2];
         Bm.m[0][0] = B[1];
-        Bm.m[0][1] = Gc;
-        Bm.m[1][0] = Gc;
+        Bm.m[0][1] = Gu;
+        Bm.m[1][0] = Gw;
         Bm.m[1][1] = B[2];
         d.v[0] = f[1];
         d.v[1] = f[2];
@@ -612,18 +671,22 @@ struct Picard3fLauncher {
         uintptr_t al = 0;
         for (int k = 0; k < 3; ++k)
             al |= reinterpret_cast<uintptr_t>(st->u[k]) | reinterpret_cast<uintptr_t>(st->um1[k]) | reinterpret_cast<uintptr_t>(st->uE[k]) |
-                  reinterpret_cast<uintptr_t>(st->DE[k]) | reinterpret_cast<uintptr_t>(st->cE[k]);
+                  reinterpret_cast<uintptr_t>(st->DE[k]) | reinterpret_cast<uintptr_t>(st->cE[k]) |
+                  (q->flux_model == TG_FLUX_EXTERNAL ? reinterpret_cast<uintptr_t>(q->flux[k]) : 0);
         const size_t tiles = (size_t)(block / 64) * kTiles3f * WaveTile<(P == 8) ? 8 : 4>::kDoubles * sizeof(double);
         const size_t cap = max_lds_bytes();
         if (lds > cap) return fail(TG_ERR_UNSUPPORTED, "grid too large for the LDS of this device%s");
         const bool full = (n == P * G::T) && (al & 15) == 0 && (P == 4 || P == 8) && (G::kBlock || G::T == 64) && lds + tiles <= cap;
         if (full) lds += tiles;
-        if (q->pseudo_time) {
-            if (full) hipLaunchKernelGGL((picard_3f_kernel<P, G, true, true>), dim3(grid), dim3(block), lds, s, *st, *q);
-            else hipLaunchKernelGGL((picard_3f_kernel<P, G, false, true>), dim3(grid), dim3(block), lds, s, *st, *q);
+        if (q->flux_model == TG_FLUX_EXTERNAL) {
+            if (full) hipLaunchKernelGGL((picard_3f_kernel<P, G, true, false, true>), dim3(grid), dim3(block), lds, s, *st, *q);
+            else hipLaunchKernelGGL((picard_3f_kernel<P, G, false, false, true>), dim3(grid), dim3(block), lds, s, *st, *q);
+        } else if (q->pseudo_time) {
+            if (full) hipLaunchKernelGGL((picard_3f_kernel<P, G, true, true, false>), dim3(grid), dim3(block), lds, s, *st, *q);
+            else hipLaunchKernelGGL((picard_3f_kernel<P, G, false, true, false>), dim3(grid), dim3(block), lds, s, *st, *q);
         } else {
-            if (full) hipLaunchKernelGGL((picard_3f_kernel<P, G, true, false>), dim3(grid), dim3(block), lds, s, *st, *q);
-            else hipLaunchKernelGGL((picard_3f_kernel<P, G, false, false>), dim3(grid), dim3(block), lds, s, *st, *q);
+            if (full) hipLaunchKernelGGL((picard_3f_kernel<P, G, true, false, false>), dim3(grid), dim3(block), lds, s, *st, *q);
+            else hipLaunchKernelGGL((picard_3f_kernel<P, G, false, false, false>), dim3(grid), dim3(block), lds, s, *st, *q);
         }
         return launch_check();
     }
@@ -654,11 +717,22 @@ int tg_block3_solve(const double *Cb, const double *Bb, const double *Ab, const 
 int tg_picard_3f_step(const tg_state_3f *st, const tg_params_3f *q, tg_stream stream) {
     if (!st || !q) return fail(TG_ERR_ARG, "NULL state or params%s");
     if (int e = check_dims(st->nb, st->n, 3)) return e;
+    if (q->flux_model != TG_FLUX_SHESTAKOV && q->flux_model != TG_FLUX_EXTERNAL) return fail(TG_ERR_ARG, "unknown flux model%s");
+    const bool ext = q->flux_model == TG_FLUX_EXTERNAL;
     for (int s = 0; s < 3; ++s) {
         if (!st->u[s] || !st->um1[s] || !st->uE[s] || !st->DE[s] || !st->cE[s]) return fail(TG_ERR_ARG, "NULL state array%s");
-        if (!q->UL[s] || !q->H7[s]) return fail(TG_ERR_ARG, "UL and H7 are required for the three fields%s");
+        if (!q->UL[s]) return fail(TG_ERR_ARG, "UL is required for the three fields%s");
+        if (!ext && !q->H7[s]) return fail(TG_ERR_ARG, "H7 is required for the three fields%s");
+        if (ext) {
+            if (!q->frozen_turb && !q->flux[s]) return fail(TG_ERR_ARG, "outside inputs: a flux array is required for the three fields%s");
+            const int64_t strides[3] = {q->h6_stride[s], q->h7_stride[s], q->h8_stride[s]};
+            for (int k = 0; k < 3; ++k)
+                if (strides[k] != 0 && strides[k] != st->n) return fail(TG_ERR_ARG, "H6, H7, H8 strides must be 0 (one array for all profiles) or n%s");
+        }
     }
-    if (!st->status || !st->iters || !q->nu0) return fail(TG_ERR_ARG, "NULL status, iters or nu0%s");
+    if (ext && q->H8[0]) return fail(TG_ERR_ARG, "the first field is solved on its own: it has no H8%s");
+    if (ext && q->pseudo_time) return fail(TG_ERR_UNSUPPORTED, "pseudo-timestep control is available with the built-in closure only%s");
+    if (!st->status || !st->iters || (!ext && !q->nu0)) return fail(TG_ERR_ARG, "NULL status, iters or nu0%s");
     if (st->err && st->err_stride <= 0) return fail(TG_ERR_ARG, "err_stride must be positive%s");
     if ((q->tread_lightly || q->tread_initial_steps > 0) && !q->pseudo_time)
         return fail(TG_ERR_ARG, "tread_lightly and tread_initial_steps need pseudo_time (the previous iterates in the u_{m-1} slots)%s");

@@ -119,6 +119,14 @@ class Fused3F(object):
     """Device-resident three-field ensemble stepped by tg_picard_3f_step."""
 
     def __init__(self, s, fields):
+        self._alloc_state(s, fields)
+        D = H.DeviceArray
+        self.nu0 = D.from_host(np.broadcast_to(np.asarray(fields[1].compute_all_H.nu0, dtype=np.float64), (self.nb,)))
+        x = np.asarray(s.x, dtype=np.float64)
+        self.H7 = [D.from_host(src(x)) for src in (source_n, source_i, source_e)]
+
+    def _alloc_state(self, s, fields):
+        """The device-resident state of the three fields (order: the field solved on its own, then the pair)."""
         self.fields = fields
         u0 = [np.atleast_2d(np.asarray(s.profiles[f.label], dtype=np.float64)) for f in fields]
         self.nb, self.n = u0[0].shape
@@ -143,9 +151,6 @@ class Fused3F(object):
         self.err = D((nb, s.maxIterations), zero=True)
         self.counts = D((4,), np.int64, zero=True)
         self.UL = [D.from_host(np.broadcast_to(np.asarray(f.rightBC, dtype=np.float64), (nb,))) for f in fields]
-        self.nu0 = D.from_host(np.broadcast_to(np.asarray(fields[1].compute_all_H.nu0, dtype=np.float64), (nb,)))
-        x = np.asarray(s.x, dtype=np.float64)
-        self.H7 = [D.from_host(src(x)) for src in (source_n, source_i, source_e)]
         P3 = H._p * 3
         ptrs = lambda arrs: P3(*[a.ptr for a in arrs])
         self.state = H.State3F(nb, n, ptrs(self.u), ptrs(self.um1), ptrs(self.uE), ptrs(self.DE), ptrs(self.cE),

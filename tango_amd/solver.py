@@ -44,7 +44,7 @@ class Solver(object):
                  useInnerIteration=False, innerIterationMaxCount=20,
                  user_control_func=None,
                  saveFluxesInMemory=False,
-                 iterationsPerCheck=1, saveProfileHistory=None, detectStaticH=True):
+                 iterationsPerCheck=1, saveProfileHistory=None, detectStaticH=True, fusedPaths=True):
         """Arguments up to saveFluxesInMemory are those of tango/solver.py:33-39.
 
         iterationsPerCheck  (fused path) iterations per kernel launch and between two host reads of the
@@ -59,6 +59,8 @@ class Solver(object):
                             (examples/shestakov_basic.py:41-53); if so the iteration runs on the fused path with the
                             flux model called on the host.  A callback can state the answer itself with an attribute
                             static_H = True / False, which suppresses the trial calls.
+        fusedPaths          False keeps the run on the generic path (one kernel per reference function, host arrays in
+                            between) whatever the problem.
         """
         self.L = L
         self.x = x
@@ -112,6 +114,7 @@ class Solver(object):
         self.saveProfileHistory = (not self.batched) if saveProfileHistory is None else saveProfileHistory
         self.iterationsPerCheck = max(1, int(iterationsPerCheck))
         self.detectStaticH = bool(detectStaticH)
+        self.fusedPaths = bool(fusedPaths)
 
         self.profilesAllTimesteps = {}
         self.fluxesAllTimesteps = {}
@@ -385,7 +388,7 @@ def is_unacceptable_one_profile(oldProfile, newProfile, maxFractionalChange=0.2,
 # ---------------------------------------------------------------------- fused path
 def _plan_fused(s):
     """Return a fused-path runner when the problem is one the fused kernels implement, else None."""
-    if s.user_control_func is not None or s.saveFluxesInMemory or s.maxIterationsPerSet != np.inf:
+    if not s.fusedPaths or s.user_control_func is not None or s.saveFluxesInMemory or s.maxIterationsPerSet != np.inf:
         return None
     if s.useTreadLightly and s.is_unacceptable_one_profile is not is_unacceptable_one_profile:
         return None      # a user-supplied acceptance test runs on the host
@@ -429,13 +432,17 @@ def _plan_fused(s):
         plan = _FusedExternal1F.plan(s)
         if plan is not None:
             return plan
-    if th.doSmoothing or th.isNonCartesian or not all(plain(f.lodestroMethod._fluxSplitter) for f in s.fields):
+    if th.isNonCartesian or not all(plain(f.lodestroMethod._fluxSplitter) for f in s.fields):
         return None
     if (s.useTreadLightly or s.useTreadInitially) and s.useInnerIteration:
         return None      # the kernels do not combine pseudo-timestep control with inner iterations
-    if model == 'threefield_nonlinear_nu' and len(s.fields) == 3:
+    if model == 'threefield_nonlinear_nu' and len(s.fields) == 3 and not th.doSmoothing:
         from .extras import threefield
-        return threefield.plan(s)
+        runner = threefield.plan(s)
+        if runner is not None:
+            return runner
+    if len(s.fields) == 3:
+        return _FusedExternal3F.plan(s)      # a field on its own + a coupled pair with a Python flux model and callbacks
     return None
 
 
@@ -1092,3 +1099,184 @@ class _FusedMapped1F(_FusedExternal1F):
             _Fused1F.finish(self, s)
         finally:
             self.uE, self.DE, self.cE = keep
+
+
+class _FusedExternal3F(object):
+    """One field solved on its own plus a pair of coupled fields (the grouping of tango/fieldgroups.py:275-331 for e.g.
+    n, pi <-> pe) whose flux model and compute_all_H callbacks are arbitrary Python: per iteration the EWMA of the three
+    profiles is advanced on the device (tg_ewma_profiles) and handed to fluxModel.get_flux on the host, the callbacks are
+    called with the current profiles for their H6, H7, H8 (e.g. the collision terms H6 = -nu, H8 = +nu of
+    examples/shestakov_threefield_nonlinearnu.py:108-149), fluxes and coefficients go back through page-locked buffers,
+    and ONE launch of tg_picard_3f_step (TG_FLUX_EXTERNAL) does the three splits, the EWMA of D and c, the assembly, the
+    residual, the tridiagonal and the 2x2 block-tridiagonal solve and the validity check
+    (tango/lodestro_method.py:327-408, tango/fieldgroups.py:172-256, tango/JK_to_matrix_fd.py:52-166,
+    tango/solver.py:188-272), where the generic path makes about ten launches per field group with host arrays in between.
+    Callbacks marked static_H = True are evaluated once.  Inner iterations (tango/solver.py:274-309) call the callbacks
+    again with the new profiles and relaunch with the turbulent coefficients frozen.
+
+    Taken when: three fields, one uncoupled and two coupled to each other; the same EWMA and theta parameters for all;
+    Cartesian geometry on the solver's own grid; callbacks that return H1 = 1 and no H2, H3, H4; no pseudo-timestep
+    control.  Anything else stays on the generic path."""
+
+    KEYS = ('H6', 'H7', 'H8')
+
+    @classmethod
+    def plan(cls, s):
+        from .extras import threefield
+        if len(s.fields) != 3 or s.useTreadLightly or s.useTreadInitially:
+            return None
+        alone = [f for f in s.fields if f.coupledTo is None]
+        pair = [f for f in s.fields if f.coupledTo is not None]
+        if len(alone) != 1 or len(pair) != 2 or pair[0].coupledTo != pair[1].label or pair[1].coupledTo != pair[0].label:
+            return None
+        fields = (alone[0], pair[0], pair[1])
+        th = s.compute_all_H_all_fields.turbhandler
+        if th.dxTurbGrid != s.dx or getattr(th.fluxModel, 'device_flux', False):
+            return None
+        params = [f.lodestroMethod.get_ewma_params() for f in fields]
+        thetas = [dict(f.lodestroMethod._fluxSplitter.thetaParams) for f in fields]
+        if len(set(params)) != 1 or any(t != thetas[0] for t in thetas):
+            return None
+        preset = [f.lodestroMethod._EWMAProfile._yEWMA_lminus1 is not None for f in fields]
+        if any(preset) and not all(preset):
+            return None
+        runner = cls.__new__(cls)
+        runner._base = threefield.Fused3F.__new__(threefield.Fused3F)
+        try:
+            coeffs = runner._call_callbacks(s, fields, {f.label: np.asarray(s.profiles[f.label], dtype=np.float64) for f in s.fields}, s.tArray[0])
+        except Exception:
+            return None
+        if coeffs is None:
+            return None
+        runner._init(s, fields, coeffs)
+        return runner
+
+    @classmethod
+    def _call_callbacks(cls, s, fields, profiles, t):
+        """The fields' own coefficients for `profiles` (tango/multifield.py:202 without the turbulent part): a list of
+        {'H6', 'H7', 'H8'} dicts of float64 arrays or None, or None if a callback returns something the kernel does not
+        take (H1 other than 1; H2, H3, H4; an H8 on the field that is solved alone)."""
+        out = []
+        for k, f in enumerate(fields):
+            Hc = f.compute_all_H(t, s.x, profiles, _mf.HCoefficients())
+            if not isinstance(Hc, _mf.HCoefficients) or Hc.H1 is None or not np.all(np.asarray(Hc.H1) == 1.0):
+                return None
+            if any(getattr(Hc, name) is not None for name in ('H2', 'H3', 'H4')) or (k == 0 and Hc.H8 is not None):
+                return None
+            out.append({name: (None if getattr(Hc, name) is None else np.ascontiguousarray(getattr(Hc, name), dtype=np.float64))
+                        for name in cls.KEYS})
+        return out
+
+    def _init(self, s, fields, coeffs):
+        b = self._base
+        b._alloc_state(s, fields)
+        self.fields, self.nb, self.n = fields, b.nb, b.n
+        nb, n = self.nb, self.n
+        self.static = all(getattr(f.compute_all_H, 'static_H', False) is True for f in fields)
+        from .ensemble import device_arrays
+        self.flux = device_arrays([((nb, n), np.float64)] * 3, zero=True)
+        # one device array and one page-locked staging buffer per coefficient the callbacks return, in the shape they
+        # return it: (n,) for all profiles or (profiles, n)
+        self.coef = [{} for _ in fields]
+        for k, c in enumerate(coeffs):
+            for name, v in c.items():
+                if v is None:
+                    continue
+                shape = (n,) if v.ndim == 1 else (nb, n)
+                if v.shape != shape and not (v.ndim == 1 and nb == 1 and v.shape == (n,)):
+                    v = np.broadcast_to(v, shape)
+                self.coef[k][name] = (H.DeviceArray(shape), H.PinnedArray(shape))
+        self._upload_coeffs(coeffs)
+        self._pin_in = [H.PinnedArray((nb, n)) for _ in range(3)]
+        self._pin_flux = [H.PinnedArray((nb, n)) for _ in range(3)]
+
+    def _upload_coeffs(self, coeffs):
+        for k, c in enumerate(coeffs):
+            if sorted(name for name, v in c.items() if v is not None) != sorted(self.coef[k]):
+                raise RuntimeError('compute_all_H of field %r returned another set of coefficients than at the start' % self.fields[k].label)
+            for name, (dev, pin) in self.coef[k].items():
+                pin.array[...] = np.broadcast_to(c[name], pin.shape)
+                pin.upload(dev)
+
+    def params(self, s):
+        b = self._base
+        m = self.fields[0].lodestroMethod
+        a_turb, a_prof = m.get_ewma_params()
+        tp = m._fluxSplitter.thetaParams
+        q = H.Params3F()
+        q.dt, q.dx, q.a_turb, q.a_prof = float(s.dt), float(s.dx), float(a_turb), float(a_prof)
+        q.Dmin, q.Dmax, q.dpdx_thr, q.tol = float(tp['Dmin']), float(tp['Dmax']), float(tp['dpdxThreshold']), float(s.tol)
+        q.UL = b._ptrs(b.UL)
+        q.flux_model = H.FLUX_EXTERNAL
+        q.flux = b._ptrs(self.flux)
+        for k in range(3):
+            for name, stride, ptrs in (('H6', q.h6_stride, q.H6), ('H7', q.h7_stride, q.H7), ('H8', q.h8_stride, q.H8)):
+                if name in self.coef[k]:
+                    dev = self.coef[k][name][0]
+                    ptrs[k] = dev.ptr
+                    stride[k] = self.n if len(dev.shape) == 2 else 0
+        return q
+
+    def _profiles_on_host(self, s, arrays):
+        """The three device arrays as the dict of host arrays the reference's callables take ((N,) for a single profile)."""
+        out = {}
+        for f, pin, d in zip(self.fields, self._pin_in, arrays):
+            a = pin.download(d)
+            out[f.label] = a if s.batched else a[0]
+        return out
+
+    def _refresh_coeffs(self, s):
+        coeffs = self._call_callbacks(s, self.fields, self._profiles_on_host(s, self._base.u), s.t)
+        if coeffs is None:
+            raise RuntimeError('a compute_all_H callback now returns coefficients the fused three-field step does not take '
+                               '(H1 other than 1, or H2, H3, H4): construct the Solver with fusedPaths=False')
+        self._upload_coeffs(coeffs)
+
+    def run_timestep(self, s):
+        b = self._base
+        q = self.params(s)
+        th = s.compute_all_H_all_fields.turbhandler
+        a_prof = self.fields[0].lodestroMethod.get_ewma_params()[1]
+        if s.m > 1:
+            for a, c in zip(b.um1, b.u):
+                a.copy_from(c)
+            b.status.set((b.status.to_host() & H.ST_SEEDED).astype(np.int32))
+            H.check(H.lib.tg_memset(b.iters.ptr, 0, b.iters.nbytes, H.stream()))
+            H.check(H.lib.tg_memset(b.err.ptr, 0, b.err.nbytes, H.stream()))
+        inner = s.innerIterationMaxCount if s.useInnerIteration else 0
+        hist = s.profilesAllIterations
+        done = start = b.start = s.iterationNumber
+        pick = (lambda a: a) if s.batched else (lambda a: a[0])
+        while done < s.maxIterations:
+            if (done - start) % s.iterationsPerCheck == 0:
+                H.check(H.lib.tg_status_reduce(b.status.ptr, self.nb, b.counts.ptr, H.stream()))
+                if int(b.counts.to_host()[0]) == 0:
+                    break
+            # EWMA of the profiles that still iterate, the flux model on it (tango/lodestro_method.py:342-362)
+            for k in range(3):
+                H.check(H.lib.tg_ewma_profiles(b.u[k].ptr, b.uE[k].ptr, float(a_prof), b.status.ptr, self.nb, self.n, H.stream()))
+            fluxes = th.fluxModel.get_flux(self._profiles_on_host(s, b.uE))
+            for f, pin, dev in zip(self.fields, self._pin_flux, self.flux):
+                flux = np.asarray(fluxes[f.label], dtype=np.float64)
+                if th.doSmoothing:
+                    flux = np.asarray(th.fluxSmoother.smooth(flux), dtype=np.float64)
+                if hist is not None and s.fluxesAllIterations is not None:
+                    s.fluxesAllIterations[f.label][done - start] = flux
+                pin.array[...] = np.atleast_2d(flux)
+                pin.upload(dev)
+            # the fields' own coefficients for the current profiles (tango/multifield.py:202)
+            if not self.static:
+                self._refresh_coeffs(s)
+            q.frozen_turb, q.outer_count = 0, 0
+            H.check(H.lib.tg_picard_3f_step(C.byref(b.state), C.byref(q), H.stream()))
+            done += 1
+            q.frozen_turb, q.outer_count = 1, done
+            for _ in range(inner):      # tango/solver.py:274-309: turbulent coefficients frozen, the callbacks see the new profiles
+                if not self.static:
+                    self._refresh_coeffs(s)
+                H.check(H.lib.tg_picard_3f_step(C.byref(b.state), C.byref(q), H.stream()))
+            if hist is not None:
+                for f, d in zip(self.fields, b.u):
+                    hist[f.label][done - 1 - start] = pick(d.to_host())
+        H.synchronize()
+        b.finish(s)

@@ -90,14 +90,28 @@ def test_block3_solve(tango, n):
     assert relerr(x1[:, 0], u0) < 1e-12 and relerr(x1[:, 1], u1) < 1e-12 and relerr(x1[:, 2], u2) < 1e-12
 
 
-def make_3f_solver(tango, N, nu0, BCs, tol=1e-9, maxit=1000, inner=0, fused=True, ic=None, ewma=(0.3, 0.3), dt=1e6, ewma_iterates=None, **kw):
+def make_3f_solver(tango, N, nu0, BCs, tol=1e-9, maxit=1000, inner=0, fused=True, ic=None, ewma=(0.3, 0.3), dt=1e6, ewma_iterates=None,
+                   external=False, order=(0, 1, 2), **kw):
     T = tango.extras.threefield
     dx = 1 / (N - 1); x = np.arange(N) * dx
     th = {'Dmin': 1e-5, 'Dmax': 1e13, 'dpdxThreshold': 10}
     ic = (1 - 0.5 * x) if ic is None else ic
     cbs = [T.ComputeAllH_n(), T.ComputeAllH_pi(nu0), T.ComputeAllH_pe(nu0)]
-    if not fused:     # plain callables -> generic path
+    model = T.ShestakovThreeFieldFluxModel(dx)
+    if not fused or external:     # plain callables, as a user's script has them (examples/shestakov_threefield_nonlinearnu.py:52-149)
         cbs = [(lambda cb: (lambda t, xx, p, HT: cb(t, xx, p, HT)))(cb) for cb in cbs]
+    if external:                  # ... and a flux model the package knows nothing about
+
+        class UserFluxModel(object):
+            def __init__(self, inner):
+                self.calls, self.inner = 0, inner
+
+            def get_flux(self, profiles):
+                self.calls += 1
+                return self.inner.get_flux(profiles)
+        model = UserFluxModel(model)
+    if not fused:
+        kw.setdefault('fusedPaths', False)      # the generic path: one kernel per reference function
     lms = [tango.lodestro_method.lm(ewma[0], ewma[1], th) for _ in range(3)]
     if ewma_iterates is not None:      # continuing an interrupted run: (profile, D, c) memories of the three fields
         for m_, its_ in zip(lms, ewma_iterates):
@@ -106,8 +120,9 @@ def make_3f_solver(tango, N, nu0, BCs, tol=1e-9, maxit=1000, inner=0, fused=True
     fields = [F(label='n', rightBC=BCs[0], profile_mminus1=1.0 * ic, compute_all_H=cbs[0], lodestroMethod=lms[0]),
               F(label='pi', rightBC=BCs[1], profile_mminus1=1.0 * ic, compute_all_H=cbs[1], lodestroMethod=lms[1], coupledTo='pe'),
               F(label='pe', rightBC=BCs[2], profile_mminus1=1.0 * ic, compute_all_H=cbs[2], lodestroMethod=lms[2], coupledTo='pi')]
+    fields = [fields[k] for k in order]
     tango.multifield.check_fields_initialize(fields)
-    call = tango.multifield.ComputeAllHAllFields(fields, tango.lodestro_method.TurbulenceHandler(dx, x, T.ShestakovThreeFieldFluxModel(dx)))
+    call = tango.multifield.ComputeAllHAllFields(fields, tango.lodestro_method.TurbulenceHandler(dx, x, model))
     return tango.solver.Solver(1, x, np.array([0, dt]), maxit, tol, call, fields, useInnerIteration=inner > 0,
                                innerIterationMaxCount=max(inner, 1), **kw), lms
 
@@ -130,6 +145,60 @@ def test_threefield_fused_matches_reference(tango, golden):
     assert abs(s.profiles['n'][0] - 3.943314) < 1e-6 and abs(s.profiles['pi'][0] - 0.325379) < 1e-6
     if len(s.errHistoryFinal) == int(g['N500_iters']):
         assert relerr(lms[1]._EWMATurbD._yEWMA_lminus1, g['N500_ewma_pi'][0]) < TOL
+
+
+@pytest.mark.parametrize('order', [(0, 1, 2), (2, 0, 1)])
+def test_threefield_outside_inputs_match_reference(tango, golden, order):
+    """The three-field example with everything problem-specific in Python, as the reference's script has it: a flux model
+    object with get_flux and plain compute_all_H functions that form the collision frequency from the current profiles.
+    The run takes the fused step with outside inputs (flux arrays, H6/H7/H8 arrays; one launch per iteration) and must
+    follow the reference's trajectory: the same 65 iterations, residual history, iterates and final profiles.  The fields
+    may be listed in any order (the pair is found by coupledTo, tango/fieldgroups.py:275-331)."""
+    from tango_amd.solver import _FusedExternal3F
+    g = golden('g9_threefield')
+    s, lms = make_3f_solver(tango, 500, 2.2, (2, 0.1, 0.3), external=True, order=order)
+    assert isinstance(s._fused, _FusedExternal3F) and not s._fused.static
+    while s.ok:
+        s.take_timestep()
+    assert s.reachedEnd and s.converged and not s.solutionError
+    assert len(s.errHistoryFinal) == int(g['N500_iters'])       # stops on the reference's iteration
+    assert s.compute_all_H_all_fields.turbhandler.fluxModel.calls == int(g['N500_iters'])
+    assert np.allclose(s.errHistoryFinal, g['N500_err'], rtol=1e-6, atol=5e-12)
+    for lab in ('n', 'pi', 'pe'):
+        assert relerr(s.profiles[lab], g[f'N500_{lab}']) < TOL and s.profiles[lab].shape == (500,)
+        assert relerr(s.profilesAllIterations[lab][0], g[f'N500_it0_{lab}']) < TOL
+        assert relerr(s.profilesAllIterations[lab][10], g[f'N500_it10_{lab}']) < TOL
+    assert relerr(lms[1]._EWMATurbD._yEWMA_lminus1, g['N500_ewma_pi'][0]) < TOL
+
+
+def test_threefield_outside_inputs_inner_iteration_and_ensemble(tango, golden):
+    """Outside inputs with inner iterations (the callbacks are called again with every new profile), and an ensemble whose
+    members have their own collision amplitude and boundary values: the same numbers as the built-in closure gives."""
+    from tango_amd.solver import _FusedExternal3F
+    g = golden('g9_threefield')
+    s, _ = make_3f_solver(tango, 500, 2.2, (2, 0.1, 0.3), inner=2, external=True)
+    assert isinstance(s._fused, _FusedExternal3F)
+    while s.ok:
+        s.take_timestep()
+    assert s.converged and len(s.errHistoryFinal) == int(g['inner_iters'])
+    for lab in ('n', 'pi', 'pe'):
+        assert relerr(s.profiles[lab], g[f'inner_{lab}']) < TOL
+        assert relerr(s.profilesAllIterations[lab][0], g[f'inner_it0_{lab}']) < TOL
+    N, nb = 256, 5
+    ens = orc.threefield_ensemble(nb, N)
+    bcs = tuple(ens['bc'][:, k].copy() for k in range(3))
+    runs = []
+    for external in (False, True):
+        s, _ = make_3f_solver(tango, N, ens['nu0'], bcs, ic=ens['u0'], external=external, iterationsPerCheck=4)
+        assert s.batched and isinstance(s._fused, _FusedExternal3F) == external
+        s.take_timestep()
+        assert s.converged
+        runs.append(s)
+    a, b = runs
+    assert np.array_equal(a.iterationsPerProfile, b.iterationsPerProfile) and len(set(a.iterationsPerProfile.tolist())) > 1
+    for lab in ('n', 'pi', 'pe'):
+        assert relerr(b.profiles[lab], a.profiles[lab]) < TOL
+    assert np.allclose(b.errHistory, a.errHistory, rtol=1e-6, atol=5e-12)
 
 
 def test_threefield_inner_iteration(tango, golden):
@@ -312,3 +381,95 @@ def test_threefield_full_size_properties(tango):
         for k, ref in enumerate((n, pi, pe)):
             assert relerr(u[k][b], ref) < TOL, (b, k)
         assert np.allclose(E.err.to_host()[b, :its], err[:its], rtol=1e-6, atol=1e-11)
+
+
+@pytest.mark.parametrize('N,nb', [(512, 3), (100, 4), (1024, 2), (64, 5)])
+def test_threefield_step_with_outside_inputs_vs_oracle(tango, N, nb):
+    """tg_picard_3f_step with TG_FLUX_EXTERNAL through the C ABI: arbitrary flux arrays, an H6 on every field, H8 that differ
+    between the two fields of the pair (so that the orientation of the coupling is pinned: H8 of the first multiplies the
+    second one's profile in the first one's equation, tango/JK_to_matrix_fd.py:97-112), H7 once per profile and once
+    shared, against the same iteration put together from the CPU oracle's pieces; two iterations, the second with
+    seeded memories, then an inner pass with the turbulent coefficients frozen."""
+    import ctypes as C
+    from tango_amd import _hip as H
+    from tango_amd.ensemble import ThreeFieldEnsemble
+    rng = np.random.default_rng(5 + N)
+    ens = orc.threefield_ensemble(nb, N)
+    x, dx, dt, a_turb, a_prof = ens['x'], ens['dx'], 1e6, 0.3, 0.4
+    theta = dict(Dmin=1e-5, Dmax=1e13, dpdxThreshold=10.0)
+    E = ThreeFieldEnsemble(ens, dt=dt, a_turb=a_turb, a_prof=a_prof, max_iter=4, fixed_count=True)
+    q = E.params
+    q.flux_model = H.FLUX_EXTERNAL
+    D = H.DeviceArray
+    u0 = [ens['u0'] * (1.0 + 0.1 * k) for k in range(3)]
+    for k in range(3):
+        E.u[k].set(u0[k]); E.um1[k].set(u0[k])
+    H7 = [rng.uniform(0, 2, (nb, N)), rng.uniform(0, 2, N), None]
+    H6 = [-rng.uniform(0, 0.5, N), -rng.uniform(1, 3, (nb, N)), -rng.uniform(1, 3, (nb, N))]
+    H8 = [None, 0.7 * -H6[1], rng.uniform(0.2, 0.9, N)[None, :] * -H6[2]]
+    keep = []
+    for k in range(3):
+        for name, arrs, ptrs, strides in (('H6', H6, q.H6, q.h6_stride), ('H7', H7, q.H7, q.h7_stride), ('H8', H8, q.H8, q.h8_stride)):
+            ptrs[k], strides[k] = None, 0
+            if arrs[k] is not None:
+                d = D.from_host(arrs[k]); keep.append(d)
+                ptrs[k], strides[k] = d.ptr, (N if arrs[k].ndim == 2 else 0)
+    flux_dev = [D((nb, N)) for _ in range(3)]
+    P3 = H._p * 3
+    q.flux = P3(*[d.ptr for d in flux_dev])
+    full = lambda a, b: np.zeros(N) if a is None else (a[b] if a.ndim == 2 else a)
+    st = [orc.State3F(u0[0][b], u0[1][b], u0[2][b]) for b in range(nb)]
+    status = np.zeros(nb, np.int32)
+    for it in range(3):
+        frozen_pass = it == 2
+        if not frozen_pass:
+            # the caller's part: EWMA of the profiles, then the flux "model" on it (here: the example's flux, perturbed)
+            for k in range(3):
+                H.check(H.lib.tg_ewma_profiles(E.u[k].ptr, E.uE[k].ptr, a_prof, E.status.ptr, nb, N, H.stream()))
+            uE = [E.uE[k].to_host() for k in range(3)]
+            fl = [f * rng.uniform(0.8, 1.2, (nb, N)) for f in orc.threefield_flux(uE[0], uE[1], uE[2], dx)]
+            for k in range(3):
+                flux_dev[k].set(fl[k])
+        q.frozen_turb, q.outer_count = int(frozen_pass), (2 if frozen_pass else 0)
+        H.check(H.lib.tg_picard_3f_step(C.byref(E.state), C.byref(q), H.stream()))
+        err = E.err.to_host()
+        for b in range(nb):
+            s3 = st[b]
+            if not frozen_pass:
+                for k, s in enumerate(s3.f):
+                    s.uE = orc.ewma_next(s.u, s.uE, a_prof)
+                    assert relerr(uE[k][b], s.uE) < TOL
+                    Dk, ck, *_ = orc.flux_split(fl[k][b], s.uE, dx, theta['Dmin'], theta['Dmax'], theta['dpdxThreshold'])
+                    s.DE, s.cE = orc.ewma_next(Dk, s.DE, a_turb), orc.ewma_next(ck, s.cE, a_turb)
+            h = [orc.dc_to_h(s.DE, s.cE) for s in s3.f]
+            one = np.ones(N)
+            fn, fi, fe = s3.f
+            bc = ens['bc'][b]
+            An, Bn, Cn, Dn = orc.h_to_matrix(dt, dx, bc[0], fn.um1, one, H2=h[0][0], H3=h[0][1], H6=full(H6[0], b), H7=full(H7[0], b))
+            Ueq, Weq = orc.jk_to_matrix(dt, dx, (bc[1], bc[2]), (fi.um1, fe.um1),
+                                        dict(H1=one, H2=h[1][0], H3=h[1][1], H6=full(H6[1], b), H7=full(H7[1], b), H8=full(H8[1], b)),
+                                        dict(H1=one, H2=h[2][0], H3=h[2][1], H6=full(H6[2], b), H7=full(H7[2], b), H8=full(H8[2], b)))
+            rms = orc.rms_of([orc.residual(An, Bn, Cn, Dn, fn.u), orc.residual(*Ueq[:4], fi.u, Ueq[4], fe.u),
+                              orc.residual(*Weq[:4], fe.u, Weq[4], fi.u)])
+            if not frozen_pass:
+                assert abs(err[b, it] - rms) <= 1e-6 * rms + 5e-12
+            fn.u = orc.tridiag_solve(An, Bn, Cn, Dn)
+            fi.u, fe.u = orc.pair_solve(Ueq, Weq)
+        for k in range(3):
+            got_u, got_D, got_c = E.u[k].to_host(), E.DE[k].to_host(), E.cE[k].to_host()
+            for b in range(nb):
+                s = st[b].f[k]
+                bar = TOL if N <= 512 else 3e-10
+                assert relerr(got_u[b], s.u) < bar, (it, k, b)
+                assert relerr(got_D[b], s.DE) < bar and relerr(got_c[b], s.cE) < bar, (it, k, b)
+    assert np.all(E.iters.to_host() == 2) and not np.any(E.status.to_host() & 6)
+    # the argument checks of the outside-input form
+    q.frozen_turb = 0
+    keepH8 = q.H8[0]
+    q.H8[0] = keep[0].ptr
+    with pytest.raises(ValueError, match='no H8'):
+        H.check(H.lib.tg_picard_3f_step(C.byref(E.state), C.byref(q), H.stream()))
+    q.H8[0] = keepH8
+    q.pseudo_time = 1
+    with pytest.raises(NotImplementedError):
+        H.check(H.lib.tg_picard_3f_step(C.byref(E.state), C.byref(q), H.stream()))
