@@ -37,6 +37,7 @@ using namespace tg;
 constexpr int kSeg = 512;        // points per segment = 64 lanes x 8 points
 constexpr int kRowQ = 4;         // doubles a lane leaves for the reduced system
 constexpr int kHaloQ = 12;       // doubles kept per segment boundary
+constexpr int kEdgeQ = 24;       // doubles a segment's two edge lanes leave for the wavefronts of the neighbouring segments
 // what a launch of the segment kernels is: an ordinary iteration; the first attempt of an iteration under pseudo-timestep
 // control (the new iterate is tentative: no verdict on its validity yet); a further attempt with half the pseudo-timestep for
 // the profiles marked in SegWork::redo (same D and c, no bookkeeping: iteration count, residual and convergence were the
@@ -54,6 +55,9 @@ struct SegWork {
     double *halo;         // (nb (S-1), 12) EWMA memories at the four points around every segment boundary, copied before a
                           // first half overwrites them: uE(j-2), uE(j-1), uE(j), uE(j+1), DE(j-1), DE(j), cE(j-1), cE(j),
                           // j = 512 (k+1); then, between two iterations of one call, the new profile at j-2 .. j+1
+    double *edge;         // (nb S, 24): the eliminated rows 0..6 of lane 0 of every segment (f, l, e: 21 values) and row 6 of
+                          // its lane 63 (f, l, e), left by a first half; from them and the lane unknowns the reduce kernel
+                          // forms the new profile next to the segment boundaries between two iterations of one call
     int32_t *flag;        // (nb,) 0: not stepped in this iteration, 1: stepped, 2: stepped and converged
     int32_t *sing;        // (nb,) zero pivot met somewhere
     // pseudo-timestep control
@@ -69,7 +73,8 @@ size_t seg_work_bytes_tread(int64_t nb, int64_t n) { return seg_work_bytes(nb, n
 
 size_t seg_work_bytes(int64_t nb, int64_t n) {
     const int64_t L = nb * n / 8, S = n / kSeg;
-    size_t b = sizeof(double) * (size_t)((kRowQ + 1) * L + 5 * nb * S + kHaloQ * nb * (S - 1)) + sizeof(double) * (size_t)nb + sizeof(int32_t) * (size_t)(4 * nb + 4);
+    size_t b = sizeof(double) * (size_t)((kRowQ + 1) * L + (5 + kEdgeQ) * nb * S + kHaloQ * nb * (S - 1)) + sizeof(double) * (size_t)nb +
+               sizeof(int32_t) * (size_t)(4 * nb + 4);
     return (b + 255) & ~(size_t)255;
 }
 
@@ -83,6 +88,7 @@ SegWork seg_carve(void *work, int64_t nb, int64_t n) {
     W.mx = p; p += nb * S;
     W.halo = p; p += kHaloQ * nb * (S - 1);
     W.first = p; p += 3 * nb * S;
+    W.edge = p; p += kEdgeQ * nb * S;
     W.dtau = p; p += nb;
     W.flag = reinterpret_cast<int32_t *>(p);
     W.sing = W.flag + nb;
@@ -164,42 +170,20 @@ __global__ void seg_halo_kernel(tg_state_1f S_, SegWork W) {
 
 // Between two iterations of one call, when the second half of the iteration and the first half of the next run in
 // one kernel, an edge lane also needs the neighbouring segment's NEW profile at the two points next to the boundary
-// before the neighbour has stored it.  One thread per side of a boundary redoes the sweep of the lane on its side
-// (rows 0..6, the same row function and elimination as the segment kernels) and its back substitution from the lane
-// unknowns y (indexed by lane within the profile), exactly as the owner of those rows will.
-// side 0: last lane of the segment on the left, 1: first lane of the segment on the right.
-// The sweep reads only what the first halves left (no lane unknowns yet) and is done before the reduced system is
-// solved, its loads next to the solver's own; boundary_finish then needs y alone.
-__device__ __forceinline__ void boundary_sweep(const tg_state_1f &S_, const tg_params_1f &Q, int64_t b, int k, int side,
-                                               ChunkElim<8, kDivRounded> &el) {
-    constexpr int P = 8;
-    const int64_t off = b * S_.n;
-    const int jb = (k + 1) * kSeg;
-    const int j0 = side ? jb : jb - P;            // the lane's first point
-    const Recip rc(Q.dx, Q.dt_b ? Q.dt_b[b] : Q.dt);
-    const double UL = Q.UL[b];
-    const double S0 = Q.H7 ? 0.0 : Q.S0[b];
-    const int src_cut = Q.H7 ? 0 : Q.src_cut[b];
-    const double *DEp = S_.DE + off, *cEp = S_.cE + off, *mp = S_.um1 + off;
-    FaceCarry c;
-    c.hm2 = (DEp[j0 - 1] + DEp[j0]) / 2.0;
-    c.hm3 = (-cEp[j0 - 1] - cEp[j0]) / 2.0;
-    c.bm = fbeta_point<kDivRounded>(c.hm2, c.hm3, rc.dx);
-    c.h2c = DEp[j0];
-    c.h3c = -cEp[j0];
-#pragma unroll
-    for (int i = 0; i < P - 1; ++i) {
-        const int j = j0 + i;
-        const double H1 = Q.H1 ? Q.H1[j] : 1.0;
-        const double h7 = Q.H7 ? Q.H7[b * Q.h7_stride + j] : ((j < src_cut) ? S0 : 0.0);
-        double A, B, C, f;
-        seg_row(c, DEp[j + 1], -cEp[j + 1], false, H1, mp[j], rc, UL, h7, true, A, B, C, f);
-        el.push(i, C, B, A, f);
-    }
+// before the neighbour has stored it.  One thread per side of a boundary (in the reduce kernel, which has the lane
+// unknowns y of the whole profile) does the back substitution of the lane on its side, x_7 = y,
+// x_i = (f_i - l_i y_left) - e_i x_{i+1}, from the eliminated rows that lane left in SegWork::edge: the same operations on
+// the same numbers as the owner of those rows will perform.
+// side 0: last lane of the segment on the left (row 6 is enough), 1: first lane of the segment on the right (rows 6..0).
+// The 21 doubles a boundary thread works from: side 1 the rows 0..6 (f, l, e) of the first lane of the segment on the
+// right, side 0 the last 21 doubles of the left segment's record, whose last three are row 6 of its lane 63.
+__device__ __forceinline__ const double *boundary_rows(const SegWork &W, int64_t b, int S, int k, int side) {
+    return W.edge + (int64_t)kEdgeQ * (b * S + k + side) + (side ? 0 : 3);
 }
 
+// rec: this thread's 21 doubles of boundary_rows; y_of_lane: the lane unknowns of the profile in lane order.
 __device__ __forceinline__ void boundary_finish(const tg_state_1f &S_, const SegWork &W, int64_t b, int k, int side,
-                                                const ChunkElim<8, kDivRounded> &el, const double *y_of_lane) {
+                                                const double *rec, const double *y_of_lane) {
     constexpr int P = 8;
     const int S = (int)(S_.n / kSeg);
     const int jb = (k + 1) * kSeg;
@@ -208,17 +192,17 @@ __device__ __forceinline__ void boundary_finish(const tg_state_1f &S_, const Seg
     const double y = y_of_lane[lane_r];
     const double yl = y_of_lane[lane_r - 1];
     if (side == 0) {
-        h[9] = y;                                                       // u(jb-1)
-        h[8] = back_step(el.f[P - 2], el.l[P - 2], el.e[P - 2], yl, y);       // u(jb-2)
+        h[9] = y;                                                  // u(jb-1)
+        h[8] = back_step(rec[18], rec[19], rec[20], yl, y);        // u(jb-2)
     } else {
         double xx = y, x1 = 0.0;
 #pragma unroll
         for (int i = P - 2; i >= 0; --i) {
-            xx = back_step(el.f[i], el.l[i], el.e[i], yl, xx);
+            xx = back_step(rec[i], rec[7 + i], rec[14 + i], yl, xx);
             if (i == 1) x1 = xx;
         }
-        h[10] = xx;                                                     // u(jb)
-        h[11] = x1;                                                     // u(jb+1)
+        h[10] = xx;                                                // u(jb)
+        h[11] = x1;                                                // u(jb+1)
     }
 }
 
@@ -230,7 +214,7 @@ __device__ __forceinline__ void boundary_finish(const tg_state_1f &S_, const Seg
 // PHASE 2: the second half of one iteration and, for profiles that go on, the first half of the next in the same
 //          wavefront: D, c, u_{m-1} and the new profile are in registers already, so the next first half reads only the
 //          profile's EWMA memory (80 instead of 115 bytes per point and iteration).  The two points of the new profile
-//          that an edge lane needs from the neighbouring segment come from the reduce kernel (boundary_sweep, boundary_finish).
+//          that an edge lane needs from the neighbouring segment come from the reduce kernel (boundary_finish).
 // wavefronts per SIMD: three (<= 168 registers) and four (<= 128) for the two halves; the combined kernel needs 216
 // registers, and with them at two per SIMD it measured 17 % faster than with 168 and 48 of them spilled
 // ARR: H1 or H7 come as arrays (otherwise H1 = 1 and H7 is the box source of the profile: no loads).
@@ -568,6 +552,25 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         double mx = 0.0, ss = 0.0;
         assemble(std::true_type{}, el, ss, mx);
 
+        // The eliminated rows the neighbouring segments' wavefronts will want between this iteration and the next one of the
+        // same call (see SegWork::edge): rows 0..6 of lane 0 and row 6 of lane 63.  They go through a 24-double record in LDS
+        // so that ONE store instruction writes them: every lane takes part in the LDS writes, all but the edge lane aiming
+        // at a spare slot, so there is no branch and the row loop above and the sweep below stay one block for the scheduler
+        // (predicated stores behind a branch made the compiler spill 20 registers here).
+        double *erec = lds + 4 * NT * Tile::kDoubles + 64 + wave * 32;
+        {
+            double *p0 = erec + (t == 0 ? 0 : 24), *p63 = erec + (t == 63 ? 21 : 25);
+#pragma unroll
+            for (int i = 0; i < P - 1; ++i) {
+                p0[i] = el.f[i];
+                p0[(t == 0 ? 7 : 0) + i] = el.l[i];
+                p0[(t == 0 ? 14 : 0) + i] = el.e[i];
+            }
+            p63[0] = el.f[P - 2];
+            p63[t == 63 ? 1 : 0] = el.l[P - 2];
+            p63[t == 63 ? 2 : 0] = el.e[P - 2];
+        }
+
         // what the reduced system needs from this lane: its last row x_last + e x_next = f - l y_left with slack rho,
         // and its first unknown x_0 = F - L y_left - E y with slack tau (ChunkElim::finish forms the same values)
         double F = el.f[P - 2], L = el.l[P - 2], E = el.e[P - 2], tau = el.rho[P - 2];
@@ -589,6 +592,19 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         (W.row[1] + lane_base)[lane_off] = own ? l7 : -(e7 * E0);
         (W.row[2] + lane_base)[lane_off] = own ? f7 : f7 - e7 * F0;
         (W.row[3] + lane_base)[lane_off] = own ? r7 : r7 - e7 * T0;
+        Tile::sync();
+        {
+            // the record, one double per lane (a buffer store: the offsets of the lanes beyond it lie outside the buffer,
+            // where the hardware drops the store)
+            double *rbase = W.edge + (int64_t)kEdgeQ * (b * S + s);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rbase, 0, kEdgeQ * (int)sizeof(double), 0x00020000);
+            const double v = erec[t < kEdgeQ ? t : 0];
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 d;
+            d.x = (unsigned)__double2loint(v);
+            d.y = (unsigned)__double2hiint(v);
+            __builtin_amdgcn_raw_buffer_store_b64(d, rs, t < kEdgeQ ? (unsigned)t * 8u : 0x7FFFF000u, 0, 0);
+        }
         mx = g.max(mx);
         ss = g.sum(ss);
         const int sing = g.any2(el.singular);
@@ -673,14 +689,18 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next, in
     }
     const int t = g.t();
     // Another iteration follows in this call: one thread per side of a segment boundary prepares what the kernel that does
-    // the second half of this iteration and the first half of the next needs there (boundary_sweep, boundary_values).
-    // Everything this takes from memory is fetched here, before the kernel's first store.
+    // the second half of this iteration and the first half of the next needs there: copies of the memories next to the
+    // boundary as the first halves have just left them (boundary_values) and the new profile there (boundary_finish, from
+    // the rows the segments' edge lanes left).  Everything this takes from memory is fetched here, before the first store.
     const bool edge = next && t < 2 * (S - 1);
-    ChunkElim<P, kDivRounded> eb;
     double bv[8];
+    double *rec = lds + 8 * G::T + rows + 21 * t;      // behind the exchange area and the lane unknowns: 21 doubles per boundary thread
     if (edge) {
         if ((t & 1) == 0) boundary_values(S_, b, t >> 1, bv);
-        boundary_sweep(S_, Q, b, t >> 1, t & 1, eb);
+        // the rows wait in LDS, not in registers, while the reduced system is solved
+        const double *src = boundary_rows(W, b, S, t >> 1, t & 1);
+#pragma unroll
+        for (int i = 0; i < 21; ++i) rec[i] = src[i];
     }
     double seg_ss = 0.0, seg_mx = 0.0;      // residual partial sums of the segments
     int it0 = 0;
@@ -720,9 +740,6 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next, in
     for (int i = 0; i < P; ++i) W.y[lane_slot(b, n, t * P + i)] = y[i];
     const int sing = g.any2(el.singular);
     if (next) {
-        // another iteration follows in this call: the boundary copies of the memories (as the first halves have just
-        // left them) and the new profile next to every boundary, for the kernel that does the second half of this
-        // iteration and the first half of the next
         double *yl = lds + 8 * G::T;      // behind the group's exchange area: the lane unknowns in lane order
 #pragma unroll
         for (int i = 0; i < P; ++i) yl[t * P + i] = y[i];
@@ -733,7 +750,7 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next, in
 #pragma unroll
                 for (int q = 0; q < 8; ++q) h[q] = bv[q];
             }
-            boundary_finish(S_, W, b, t >> 1, t & 1, eb, yl);
+            boundary_finish(S_, W, b, t >> 1, t & 1, rec, yl);
         }
     }
 
@@ -792,12 +809,19 @@ int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
     const int64_t segs = nb * (n / kSeg);
     const unsigned grid = (unsigned)((segs + 3) / 4);
     const size_t tile = 4 * WaveTile<8>::kDoubles * sizeof(double);     // one tile for each of the four wavefronts
-    const size_t lds0 = 3 * tile + 4 * 16 * sizeof(double), lds1 = 2 * tile;      // + the edge lanes' parking places of the combined kernel
+    // + the edge lanes' parking places of the combined kernel + the records of the edge lanes' rows (32 doubles per wavefront)
+    const size_t lds0 = 3 * tile + 4 * 16 * sizeof(double) + 4 * 32 * sizeof(double), lds1 = 2 * tile;
     const int64_t bounds = nb * (n / kSeg - 1);
     const int lanes = n / 64;      // threads of the reduce kernel: 8 reduced rows each
     const size_t lds_r = sizeof(double) * 8 * (size_t)lanes;
     if (lanes != 64 && lanes != 128 && lanes != 256 && lanes != 512) return fail(TG_ERR_UNSUPPORTED, "segmented form: n must be 4096, 8192, 16384 or 32768%s");
-    const size_t lds_n = lds_r + sizeof(double) * (size_t)(n / 8);       // + the lane unknowns of the profile
+    // + the lane unknowns of the profile + the rows of the boundary threads
+    const size_t lds_n = lds_r + sizeof(double) * (size_t)(n / 8) + sizeof(double) * 21 * 2 * (size_t)(n / kSeg - 1);
+    if (q->iters_per_launch > 1 && !q->pseudo_time && lds_n > 64 * 1024) {
+        // the longest profiles: the reduce kernel's LDS goes beyond what a launch may use without asking
+        if (lds_n > max_lds_bytes()) return fail(TG_ERR_UNSUPPORTED, "segmented form: not enough LDS for several iterations per call at this profile length%s");
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&picard_seg_reduce_kernel<BlockGroup<512>>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n));
+    }
     auto reduce = [&](const tg_state_1f &state, const tg_params_1f &p, int next, int mode) {
         const size_t l = next ? lds_n : lds_r;
         switch (lanes) {

@@ -850,10 +850,10 @@ def test_segmented_long_profiles_match_the_workgroup_kernel(tango, N, nb):
         assert np.allclose(A.err.to_host()[:, :k], B.err.to_host()[:, :k], rtol=1e-5, atol=1e-11)
 
 
-@pytest.mark.parametrize('N,nb', [(8192, 5), (16384, 2)])
+@pytest.mark.parametrize('N,nb', [(8192, 5), (16384, 2), (32768, 2)])
 def test_segmented_multi_iteration_launch_equals_single_launches(tango, N, nb):
     """k iterations of the segmented form in one call (the second half of an iteration and the first half of the next in
-    one kernel, the neighbouring segments' boundary values recomputed from their multipliers) against k calls of one
+    one kernel, the neighbouring segments' boundary values formed from the eliminated rows their edge lanes left) against k calls of one
     iteration: bit for bit the same profiles, EWMA memories, residual histories, stop iterations and status."""
     from tango_amd.ensemble import OneFieldEnsemble, shestakov_ensemble
     ens = shestakov_ensemble(nb, N)
