@@ -79,9 +79,27 @@ def spawn_ranks(n):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for line in (out or '').splitlines():
+    # A rank that dies leaves the others waiting in a collective for as long as the backend's timeout lasts: watch them
+    # all, and when one has failed end the others (these exact processes) instead of waiting with them.
+    import threading
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            time.sleep(2.0)      # let the others fail by themselves if they are about to
+            for r, p in enumerate(procs):
+                if p.poll() is None:
+                    p.kill()
+                codes[r] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=5)
+    for line in ''.join(x or '' for x in out).splitlines():
         print(line, flush=True)
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
@@ -211,6 +229,10 @@ def main():
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))         # nothing in this process has touched a GPU
+    if os.environ.get('TANGO_BENCH_WATCHDOG', '').isdigit():
+        # a run that has not finished after this many seconds writes where every thread stands to stderr and ends
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['TANGO_BENCH_WATCHDOG']), exit=True)
 
     import torch
     import torch.distributed as dist

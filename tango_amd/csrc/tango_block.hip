@@ -429,7 +429,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
         for (int s = 0; s < 3; ++s) load_chunk<P, false>(S_.um1[s] + off, n, j0, um1[s], 0.0);
     }
 
-    // Upwinding weights (tango/HToMatrixFD.py:277-297).  Where diffusion dominates, H2 >= |H3| dx / 2 with H3 != 0, the
+    // Upwinding weights (tango/HToMatrixFD.py:277-297); faces with H3 = 0 need none either (weight_is_moot, tg_assemble.h).  Where diffusion dominates, H2 >= |H3| dx / 2 with H3 != 0, the
     // weight is 1/2 whatever the quotient H2 / (c dx) (the test is exact: halving is, and the rounded quotient is monotone
     // in its operands).  When that holds at every face of the three fields that this wavefront uses, the quotients are
     // skipped (a branch the whole wavefront takes or not); weights and rows are the same numbers either way.  The face left
@@ -438,7 +438,7 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
     bool half = true;
     {
         // (plain & and |: evaluated for every face, no branch per face)
-        auto dominated = [&](double h2, double h3) { return bool((h3 != 0.0) & (h2 >= 0.5 * fabs(h3 * rc.dx))); };
+        auto dominated = [&](double h2, double h3) { return weight_is_moot(h2, h3, rc.dx); };
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if (!lane_first && (FULL || j0 < n - 1)) half = half & dominated((h2l[s] + DE[s][0]) / 2.0, (h3l[s] + -cE[s][0]) / 2.0);

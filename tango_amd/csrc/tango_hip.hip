@@ -1256,7 +1256,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         bool settled = done;
         bool tread_limit = false;
         double dtau = dt_full;
-        // Upwinding weights (tango/HToMatrixFD.py:277-297).  Where diffusion dominates, H2 >= |H3| dx / 2 with
+        // Upwinding weights (tango/HToMatrixFD.py:277-297); faces with H3 = 0 need none either (weight_is_moot, tg_assemble.h).  Where diffusion dominates, H2 >= |H3| dx / 2 with
         // H3 != 0, betaStar = 1 - H2/(c dx) <= 1/2 for c > 0 and -H2/(c dx) >= 1/2 for c < 0, so the weight is 1/2
         // whatever the quotient (the test is exact: halving is, and the rounded quotient is monotone in its
         // operands).  When that holds at every half point the wavefront uses, the quotients are skipped; the weights
@@ -1266,7 +1266,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         bool half = true;
         {
             // (plain & and |: evaluated for every face, no branch per face)
-            auto dominated = [&](double h2, double h3) { return bool((h3 != 0.0) & (h2 >= 0.5 * fabs(h3 * rc.dx))); };
+            auto dominated = [&](double h2, double h3) { return weight_is_moot(h2, h3, rc.dx); };
             if (!lane_first && (FULL || j0 < n - 1)) half = dominated((h2l + h2first) / 2.0, (h3l + h3first) / 2.0);
             double a2 = h2first, a3 = h3first;
 #pragma unroll

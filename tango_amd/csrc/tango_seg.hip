@@ -311,7 +311,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
             u[0] = edge_l ? h_u : ul;
             u[P + 1] = edge_r ? h_u : ur;
         }
-        // Upwinding weights (tango/HToMatrixFD.py:277-297).  Where diffusion dominates, H2 >= |H3| dx / 2 with H3 != 0, the
+        // Upwinding weights (tango/HToMatrixFD.py:277-297); faces with H3 = 0 need none either (weight_is_moot, tg_assemble.h).  Where diffusion dominates, H2 >= |H3| dx / 2 with H3 != 0, the
         // weight is 1/2 whatever the quotient H2 / (c dx) (the test is exact: halving is, and the rounded quotient is monotone
         // in its operands).  When that holds at every face this wavefront uses, the quotients are skipped (a branch the whole
         // wavefront takes or not); weights and rows are the same numbers either way.  The face left of the profile's first
@@ -319,7 +319,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         bool half = true;
         {
             // (plain & and |: evaluated for every face, no branch per face)
-            auto dominated = [&](double h2, double h3) { return bool((h3 != 0.0) & (h2 >= 0.5 * fabs(h3 * rc.dx))); };
+            auto dominated = [&](double h2, double h3) { return weight_is_moot(h2, h3, rc.dx); };
             if (!first_lane) half = dominated((h2l + DE[0]) / 2.0, (h3l - cE[0]) / 2.0);
             double a2 = DE[0], a3 = -cE[0];
 #pragma unroll

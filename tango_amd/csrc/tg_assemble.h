@@ -109,6 +109,18 @@ __device__ __forceinline__ double fbeta_point(double H2h, double H3h, double dx)
     return (c > 0.0) ? bp : ((c < 0.0) ? bn : 0.0);
 }
 
+// A face at which the upwinding weight need not be computed, 1/2 standing in for it with the same rows bit for bit:
+//  - diffusion dominates, H2 >= |H3| dx / 2 with H3 != 0: betaStar = 1 - H2/(c dx) <= 1/2 for c > 0 and -H2/(c dx) >= 1/2
+//    for c < 0, so the weight IS 1/2 whatever the quotient (the test is exact: halving is, and the rounded quotient is
+//    monotone in its operands);
+//  - H3 == 0 (no convective part at this face: theta = 1 everywhere, as with the example scripts' thetaParams): fbeta gives
+//    0 there, but the weight only ever multiplies H3 (fd_row), and a zero times any finite non-negative weight is the same
+//    zero, sign included.
+// NaN operands compare false: such a face takes the quotient, as before.  Plain & and |: no branch per face.
+__device__ __forceinline__ bool weight_is_moot(double h2, double h3, double dx) {
+    return bool((h3 == 0.0) | (h2 >= 0.5 * fabs(h3 * dx)));
+}
+
 // tango/derivatives.py:20-24: centred difference with two-point one-sided ends.
 // um, u0, up are the values at j-1, j, j+1 (um unused at the first point, up at the last).
 template <bool EXACT>

@@ -22,7 +22,9 @@ def init_from_env(backend=None):
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        # a rank that has died must not keep the others waiting for half an hour in a 40-byte all-reduce
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get('TANGO_COLLECTIVE_TIMEOUT', '300'))))
     return rank, world, local
 
 

@@ -224,7 +224,13 @@ def test_bench_two_ranks_share_the_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5', '--backend', 'gloo',
            '--config', 'c5', '--profiles-per-gpu', '4096', '--clock-warmup-ms', '5']
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=170)
+    env['TANGO_COLLECTIVE_TIMEOUT'] = '60'
+    env['TANGO_BENCH_WATCHDOG'] = '100'       # a stuck rank reports where it stands and ends; bench.py then ends the other
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=150)
+    except subprocess.TimeoutExpired as e:
+        err = e.stderr.decode(errors='replace') if isinstance(e.stderr, bytes) else (e.stderr or '')
+        raise AssertionError('bench.py --gpus 2 did not finish: ' + err[-3000:])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
