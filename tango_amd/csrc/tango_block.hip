@@ -51,19 +51,19 @@ pair_solve_kernel(PairArgs a, int64_t nb, int n, int32_t *__restrict__ status) {
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int j = j0 + i;
-        Mat<2> Cm = mat_zero<2>(), Bm, Am = mat_zero<2>();
-        Vec<2> d;
-        Cm.m[0][0] = (j == 0) ? 0.0 : cu[i];
-        Cm.m[1][1] = (j == 0) ? 0.0 : cw[i];
-        Am.m[0][0] = (j == n - 1) ? 0.0 : au[i];
-        Am.m[1][1] = (j == n - 1) ? 0.0 : aw[i];
+        Mat<2> Bm;
+        Vec<2> cv, av, d;
+        cv.v[0] = (j == 0) ? 0.0 : cu[i];
+        cv.v[1] = (j == 0) ? 0.0 : cw[i];
+        av.v[0] = (j == n - 1) ? 0.0 : au[i];
+        av.v[1] = (j == n - 1) ? 0.0 : aw[i];
         Bm.m[0][0] = bu[i];
         Bm.m[0][1] = gw[i];
         Bm.m[1][0] = gu[i];
         Bm.m[1][1] = bw[i];
         d.v[0] = du[i];
         d.v[1] = dw[i];
-        el.push(i, Cm, Bm, Am, d);
+        el.push_diag(i, cv, Bm, av, d);
     }
     Vec<2> x[P];
     el.finish(g, x);
@@ -529,19 +529,19 @@ picard_3f_kernel(tg_state_3f S_, tg_params_3f Q) {
             mx[s] = fmax(mx[s], valid ? fabs(f[s]) : 0.0);
         }
         eln.push(i, C[0], B[0], A[0], f[0]);
-        Mat<2> Cm = mat_zero<2>(), Bm, Am = mat_zero<2>();
-        Vec<2> d;
-        Cm.m[0][0] = C[1];
-        Cm.m[1][1] = C[2];
-        Am.m[0][0] = A[1];
-        Am.m[1][1] = A[2];
+        Mat<2> Bm;
+        Vec<2> cv, av, d;
+        cv.v[0] = C[1];
+        cv.v[1] = C[2];
+        av.v[0] = A[1];
+        av.v[1] = A[2];
         Bm.m[0][0] = B[1];
         Bm.m[0][1] = Gu;
         Bm.m[1][0] = Gw;
         Bm.m[1][1] = B[2];
         d.v[0] = f[1];
         d.v[1] = f[2];
-        elp.push(i, Cm, Bm, Am, d);
+        elp.push_diag(i, cv, Bm, av, d);
     }
     // rms of the three normalised residuals (tango/solver.py:464-470): the first solve's matrix decides
     if (attempt == 0) {

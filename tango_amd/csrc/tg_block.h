@@ -269,6 +269,62 @@ struct BlockElim {
         rho[i] = mul(Di, tv);
     }
 
+    // The same for DIAGONAL off-diagonal blocks C = diag(c), A = diag(a), as the transport systems have them (fields couple
+    // only through B: tango/JK_to_matrix_fd.py:80-82): the products with the structural zeros of C and A, which the compiler
+    // may not drop (0 x is not 0 for every x), are not formed.  For finite operands the results are those of push, bit for
+    // bit: the dropped terms are exact zeros added to a sum.
+    __device__ __forceinline__ void push_diag(int i, const Vec<K> &c, const Mat<K> &B, const Vec<K> &a, const Vec<K> &d) {
+        Vec<K> dlt;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < K; ++q) s += (q == r) ? (B.m[r][q] + a.v[r]) + c.v[r] : B.m[r][q];
+            dlt.v[r] = s;
+        }
+        Mat<K> Den = B, CL;
+        Vec<K> rhs = d, tv = dlt, cl1;
+        const int k = i > 0 ? i - 1 : 0;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            if (i > 0) {
+                double ls = 0.0;
+#pragma unroll
+                for (int q = 0; q < K; ++q) {
+                    Den.m[r][q] = B.m[r][q] - c.v[r] * E[k].m[r][q];
+                    CL.m[r][q] = -(c.v[r] * L[k].m[r][q]);
+                    ls += L[k].m[r][q];
+                }
+                rhs.v[r] = d.v[r] - c.v[r] * f[k].v[r];
+                tv.v[r] = dlt.v[r] - c.v[r] * rho[k].v[r];
+                cl1.v[r] = c.v[r] * ls;
+            } else {
+#pragma unroll
+                for (int q = 0; q < K; ++q) CL.m[r][q] = (q == r) ? c.v[r] : 0.0;      // -C L_{-1} with L_{-1} = -I
+                cl1.v[r] = -c.v[r];
+            }
+        }
+        Vec<K> rs;
+#pragma unroll
+        for (int r = 0; r < K; ++r) rs.v[r] = (tv.v[r] - a.v[r]) + cl1.v[r];
+        diag_from_rowsum(Den, rs);
+        const Mat<K> Di = inverse<FAST>(Den, singular);
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+#pragma unroll
+            for (int q = 0; q < K; ++q) E[i].m[r][q] = Di.m[r][q] * a.v[q];
+        f[i] = mul(Di, rhs);
+        if (i > 0) {
+            L[i] = mul(Di, CL);
+        } else {
+#pragma unroll
+            for (int r = 0; r < K; ++r)
+#pragma unroll
+                for (int q = 0; q < K; ++q) L[i].m[r][q] = Di.m[r][q] * c.v[q];
+        }
+        rho[i] = mul(Di, tv);
+    }
+
     template <class G>
     __device__ __forceinline__ void finish(const G &g, Vec<K> (&x)[P]) {
         Mat<K> S, Pm;
