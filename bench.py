@@ -108,6 +108,24 @@ def spawn_ranks(n):
     return 0
 
 
+def moved_into(struct, lo, nbytes, delta):
+    """A copy of a ctypes parameter block in which every device pointer into [lo, lo + nbytes) is moved by delta: the
+    same block for a byte-for-byte copy of that memory range."""
+    import ctypes as C
+    new = type(struct).from_buffer_copy(struct)
+    for name, ctype in struct._fields_:
+        if ctype is C.c_void_p:
+            v = getattr(struct, name)
+            if v and lo <= v < lo + nbytes:
+                setattr(new, name, v + delta)
+        elif isinstance(ctype, type) and issubclass(ctype, C.Array) and ctype._type_ is C.c_void_p:
+            arr = getattr(new, name)
+            for k, v in enumerate(getattr(struct, name)):
+                if v and lo <= v < lo + nbytes:
+                    arr[k] = v + delta
+    return new
+
+
 def cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -288,9 +306,9 @@ def main():
 
     def run(nsteps):
         """Up to nsteps Picard iterations: launches of kper iterations (a shorter one at the end if needed), a
-        convergence check every `check` steps; the loop ends early when a check found nothing left to iterate.  A run
-        shorter than the check interval still ends with one check (device reductions + all-reduces + copy), so that
-        no timed region, however few its steps, goes without the collective."""
+        convergence check every `check` steps; the loop ends early when a check found nothing left to iterate.  With
+        several ranks a run shorter than the check interval still ends with one check (device reductions + all-reduces
+        + copy), so that no timed region, however few its steps, goes without the collective."""
         done = 0
         issued = mon.issued
         while done < nsteps:
@@ -301,7 +319,7 @@ def main():
                 if nothing_left():
                     break
                 mon.issue()
-        if mon.issued == issued and nsteps > 0:
+        if world > 1 and mon.issued == issued and nsteps > 0:
             nothing_left()
             mon.issue()
         return done
@@ -325,22 +343,29 @@ def main():
     # same 20-iteration launch (22 403 vector instructions per wavefront either way, counted with rocprofv3) takes 4.0 ms
     # after 5 warm-up steps, 3.5 ms after 128 and 3.25 ms after 256 or more.  The requested warm-up can be that short
     # (5 steps = 1 ms), so the clock is brought up by further untimed launches right before the timed region; they are
-    # neither warm-up steps nor timed steps, are reported as clock_warmup_iterations, and leave nothing behind: the whole
-    # state pool (profiles, EWMA memories, status, iteration counters, residual history) is copied aside before them and put
-    # back afterwards, so the timed steps are iterations warmup .. warmup+steps-1 of the ensemble's own trajectory.
+    # neither warm-up steps nor timed steps, are reported as clock_warmup_iterations, and touch nothing of the ensemble:
+    # they step a COPY of the whole state pool (profiles, EWMA memories, status, iteration counters, residual history, work
+    # space; the same kernels on the same numbers), so the timed steps are iterations warmup .. warmup+steps-1 of the
+    # ensemble's own trajectory.
     clock_warmup = 0
     if args.clock_warmup_ms > 0:
         barrier()                                # start together, so that the ranks also reach the timed region's barrier together
-        saved = torch.empty(E.pool.nbytes, dtype=torch.uint8, device=dev)
-        H.check(H.lib.tg_copy_d2d(saved.data_ptr(), E.pool.ptr, E.pool.nbytes, stream.cuda_stream))
-        t_up = time.perf_counter()
-        while (time.perf_counter() - t_up) * 1e3 < args.clock_warmup_ms:
-            for _ in range(4):
+        twin = torch.empty(E.pool.nbytes, dtype=torch.uint8, device=dev)
+        H.check(H.lib.tg_copy_d2d(twin.data_ptr(), E.pool.ptr, E.pool.nbytes, stream.cuda_stream))
+        real = (E.state, E.params)
+        E.state, E.params = (moved_into(v, E.pool.ptr, E.pool.nbytes, twin.data_ptr() - E.pool.ptr) for v in real)
+        try:
+            t_up = time.perf_counter()
+            while (time.perf_counter() - t_up) * 1e3 < args.clock_warmup_ms:
+                for _ in range(4):
+                    E.step(stream.cuda_stream, iters=kper)
+                    clock_warmup += kper
+                torch.cuda.synchronize()
+            for _ in range(2):
                 E.step(stream.cuda_stream, iters=kper)
                 clock_warmup += kper
-            torch.cuda.synchronize()
-        H.check(H.lib.tg_copy_d2d(E.pool.ptr, saved.data_ptr(), E.pool.nbytes, stream.cuda_stream))
-        del saved
+        finally:
+            E.state, E.params = real
     fence()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     issued_before = mon.issued
@@ -371,7 +396,7 @@ def main():
 
     t = torch.tensor([wall, ev_ms, k1_ms or 0.0], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        D.allreduce_max(t)
     wall, ev_ms, k1_max = float(t[0]), float(t[1]), float(t[2])
     bad = int(np.count_nonzero(E.status.to_host() & 6))
     mon.issue()

@@ -28,11 +28,24 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def _all_reduce(t, op):
+    """In-place all-reduce of a small tensor.  RCCL (backend nccl) reduces device tensors on the current stream; gloo
+    is handed a host copy (the call then waits for the stream: gloo is the rehearsal and test backend, and its own
+    handling of device tensors stalled now and then with two ranks sharing a GPU)."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend() != 'nccl':
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+
+
 def allreduce_counts(counts):
     """Sum the per-shard counters (a torch int64 tensor of 4 entries, on the GPU for nccl) over all ranks."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        _all_reduce(counts, dist.ReduceOp.SUM)
     return counts
 
 
@@ -42,15 +55,15 @@ def allreduce_residual(summary):
     first three add up, the last two take the maximum.  Two collectives of 24 and 16 bytes, in place."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(summary[:3], op=dist.ReduceOp.SUM)
-        dist.all_reduce(summary[3:], op=dist.ReduceOp.MAX)
+        _all_reduce(summary[:3], dist.ReduceOp.SUM)
+        _all_reduce(summary[3:], dist.ReduceOp.MAX)
     return summary
 
 
 def allreduce_max(value):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(value, op=dist.ReduceOp.MAX)
+        _all_reduce(value, dist.ReduceOp.MAX)
     return value
 
 

@@ -198,7 +198,7 @@ def test_bench_line(extra):
     assert out['n_gpus'] == 1 and out['steps'] == 24 and out['value'] > 0 and out['invalid_profiles'] == 0
     shape = out['config']['launch_shape']
     k = shape['iterations_per_launch']
-    assert shape['launches_in_timed_region'] == -(-24 // k) and shape['all_reduce_rounds_in_timed_region'] == max(1, 24 // shape['check_every'])
+    assert shape['launches_in_timed_region'] == -(-24 // k) and shape['all_reduce_rounds_in_timed_region'] == 24 // shape['check_every']
     roof = out['roofline']
     # one iteration per launch crosses HBM every iteration, and so does the segmented form's chain of kernels (c4); only the
     # register-resident multi-iteration kernel is bound by fp64 issue
