@@ -103,3 +103,34 @@ def check_if_should_restart(basename=None):
                              + os.getcwd())
         basename = starts.pop()
     return find_latest_savefile(basename)
+
+
+def combine_savefiles(basename='tangodata'):
+    """Combine the save files `<basename>_s<number>.npz` of the current directory into `<basename>_combined.npz`, in
+    increasing set number (tango/restart.py:164-212 does this for its HDF5 history files: the datasets of the later files
+    are appended along the first axis).  Every save file here holds one write (the state after its last iteration), so
+    the combined file has one row per set: `iterationNumber`, `t`, `timestepNumber`, `setNumber` of shape (sets,) and
+    `<label>/<dataset>` of shape (sets,) + the dataset's own shape.  Returns the file name."""
+    start = basename + '_s'
+    found = []
+    for f in os.listdir(os.getcwd()):
+        stem, ext = os.path.splitext(f)
+        if ext == '.npz' and stem.startswith(start) and stem[len(start):].isdigit():
+            found.append((int(stem[len(start):]), f))
+    if not found:
+        raise ValueError('no files found.')
+    rows = []
+    for _, f in sorted(found):
+        (setNumber, iterationNumber, t, timestepNumber), per = _read_npz(f)
+        rows.append((setNumber, iterationNumber, t, timestepNumber, per))
+    labels = list(rows[0][4]['profile'])
+    if any(list(r[4]['profile']) != labels for r in rows):
+        raise ValueError('the save files do not hold the same fields')
+    out = {'labels': np.array(labels), 'setNumber': np.array([r[0] for r in rows]), 'iterationNumber': np.array([r[1] for r in rows]),
+           't': np.array([r[2] for r in rows]), 'timestepNumber': np.array([r[3] for r in rows])}
+    for lab in labels:
+        for key in FIELD_KEYS:
+            out[f'{lab}/{key}'] = np.stack([np.asarray(r[4][key][lab]) for r in rows])
+    filename = basename + '_combined.npz'
+    np.savez(filename, **out)
+    return filename

@@ -273,3 +273,22 @@ def test_short_quotient_rounds_like_a_division():
         assert got == want, (n.hex(), d.hex())
         beyond_one_ulp += abs(F(q) - F(n) / F(d)) > F(math.ulp(want))
     assert beyond_one_ulp > 0       # the sample does contain first products more than an ulp off: the correction step is what rounds
+
+
+def test_combine_savefiles(tmp_path, monkeypatch):
+    """restart.combine_savefiles stacks the per-set save files in set order (tango/restart.py:164-212)."""
+    from tango_amd import restart
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(ValueError, match='no files found'):
+        restart.combine_savefiles('run')
+    for k in (2, 0, 1):
+        data = {'setNumber': k, 't': 1e4, 'timestepNumber': 1, 'iterationNumber': 10 * k + 9, 'labels': np.array(['n'])}
+        for key in restart.FIELD_KEYS:
+            data[f'n/{key}'] = np.full(5, float(k))
+        np.savez(f'run_s{k}.npz', **data)
+    name = restart.combine_savefiles('run')
+    assert name == 'run_combined.npz'
+    with np.load(name) as z:
+        assert z['iterationNumber'].tolist() == [9, 19, 29] and z['setNumber'].tolist() == [0, 1, 2]
+        assert z['n/profile'].shape == (3, 5) and z['n/profile'][:, 0].tolist() == [0.0, 1.0, 2.0]
+    assert restart.find_latest_savefile('run') == 'run_s2.npz'       # the combined file is not a set
