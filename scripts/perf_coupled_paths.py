@@ -6,7 +6,9 @@ and the generic path (one kernel per reference function, host arrays in between)
     python scripts/perf_coupled_paths.py [profiles] [N] [iterations]"""
 import json, os, sys, time
 import numpy as np
+import torch          # before tango_amd: the device path below shares torch's HIP runtime with the library
 sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
 import tango_amd as tango
 from tango_amd import _hip as H
 from tango_amd.ensemble import threefield_ensemble
@@ -30,7 +32,22 @@ class UserFlux(object):
         return out
 
 
-for name, external, kw in (('built-in closure', False, {}), ('outside inputs, fused step', True, {}), ('generic path', True, {'fusedPaths': False})):
+import device_coupled_case as DC          # a torch flux model and torch collision terms (tests/device_coupled_case.py)
+
+for name, external, kw in (('built-in closure', False, {}), ('outside inputs, fused step', True, {}), ('generic path', True, {'fusedPaths': False}),
+                           ('outside inputs on the GPU (torch flux model and callbacks), fused step', 'device', {})):
+    if external == 'device':
+        s, _ = DC.build(n, ens['nu0'], tuple(ens['bc'][:, k].copy() for k in range(3)), ic=ens['u0'], iterationsPerCheck=8, saveProfileHistory=False)
+        s.maxIterations, s.tol = its, 1e-30
+        s.errHistory = np.zeros(its)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.take_timestep()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        print(json.dumps({'path': name, 'runner': type(s._fused).__name__, 'profiles': nb, 'N': n, 'iterations': its,
+                          'ms_per_iteration': round(wall / its * 1e3, 2)}), flush=True)
+        continue
     cbs = [T.ComputeAllH_n(), T.ComputeAllH_pi(ens['nu0']), T.ComputeAllH_pe(ens['nu0'])]
     spent = [0.0]
     if external:

@@ -1114,6 +1114,10 @@ class _FusedExternal3F(object):
     Callbacks marked static_H = True are evaluated once.  Inner iterations (tango/solver.py:274-309) call the callbacks
     again with the new profiles and relaunch with the turbulent coefficients frozen.
 
+    A flux model on the GPU (device_flux = True) and callbacks marked device_H = True are handed CUDA torch tensors that
+    view this solver's memory ((profiles, N), or (N,) for a single profile) and may return CUDA tensors; with both, nothing
+    crosses PCIe inside the iteration.
+
     Taken when: three fields, one uncoupled and two coupled to each other; the same EWMA and theta parameters for all;
     Cartesian geometry on the solver's own grid; callbacks that return H1 = 1 and no H2, H3, H4; no pseudo-timestep
     control.  Anything else stays on the generic path."""
@@ -1131,7 +1135,7 @@ class _FusedExternal3F(object):
             return None
         fields = (alone[0], pair[0], pair[1])
         th = s.compute_all_H_all_fields.turbhandler
-        if th.dxTurbGrid != s.dx or getattr(th.fluxModel, 'device_flux', False):
+        if th.dxTurbGrid != s.dx or (getattr(th.fluxModel, 'device_flux', False) and th.doSmoothing):
             return None
         params = [f.lodestroMethod.get_ewma_params() for f in fields]
         thetas = [dict(f.lodestroMethod._fluxSplitter.thetaParams) for f in fields]
@@ -1142,8 +1146,17 @@ class _FusedExternal3F(object):
             return None
         runner = cls.__new__(cls)
         runner._base = threefield.Fused3F.__new__(threefield.Fused3F)
+        runner.device_model = bool(getattr(th.fluxModel, 'device_flux', False))
+        runner.device_cb = [bool(getattr(f.compute_all_H, 'device_H', False)) for f in fields]
+        host_profiles = {f.label: np.asarray(s.profiles[f.label], dtype=np.float64) for f in s.fields}
+        dev_profiles = None
+        if runner.device_model or any(runner.device_cb):
+            import torch
+            if not torch.cuda.is_available():
+                return None
+            dev_profiles = {lab: torch.as_tensor(v, device='cuda') for lab, v in host_profiles.items()}
         try:
-            coeffs = runner._call_callbacks(s, fields, {f.label: np.asarray(s.profiles[f.label], dtype=np.float64) for f in s.fields}, s.tArray[0])
+            coeffs = runner._call_callbacks(s, fields, host_profiles, s.tArray[0], dev_profiles)
         except Exception:
             return None
         if coeffs is None:
@@ -1151,20 +1164,31 @@ class _FusedExternal3F(object):
         runner._init(s, fields, coeffs)
         return runner
 
-    @classmethod
-    def _call_callbacks(cls, s, fields, profiles, t):
+    def _call_callbacks(self, s, fields, profiles, t, dev_profiles=None, only=None):
         """The fields' own coefficients for `profiles` (tango/multifield.py:202 without the turbulent part): a list of
-        {'H6', 'H7', 'H8'} dicts of float64 arrays or None, or None if a callback returns something the kernel does not
-        take (H1 other than 1; H2, H3, H4; an H8 on the field that is solved alone)."""
+        {'H6', 'H7', 'H8'} dicts of float64 arrays (CUDA tensors from callbacks marked device_H) or None, or None if a
+        callback returns something the kernel does not take (H1 other than 1; H2, H3, H4; an H8 on the field that is solved
+        alone).  only: the indices of the fields to call (the others get None entries)."""
         out = []
         for k, f in enumerate(fields):
-            Hc = f.compute_all_H(t, s.x, profiles, _mf.HCoefficients())
-            if not isinstance(Hc, _mf.HCoefficients) or Hc.H1 is None or not np.all(np.asarray(Hc.H1) == 1.0):
+            if only is not None and k not in only:
+                out.append(None)
+                continue
+            Hc = f.compute_all_H(t, s.x, dev_profiles if self.device_cb[k] else profiles, _mf.HCoefficients())
+            if not isinstance(Hc, _mf.HCoefficients) or Hc.H1 is None:
+                return None
+            ones = (Hc.H1 == 1.0).all() if hasattr(Hc.H1, 'is_cuda') else np.all(np.asarray(Hc.H1) == 1.0)
+            if not bool(ones):
                 return None
             if any(getattr(Hc, name) is not None for name in ('H2', 'H3', 'H4')) or (k == 0 and Hc.H8 is not None):
                 return None
-            out.append({name: (None if getattr(Hc, name) is None else np.ascontiguousarray(getattr(Hc, name), dtype=np.float64))
-                        for name in cls.KEYS})
+            row = {}
+            for name in self.KEYS:
+                v = getattr(Hc, name)
+                if v is not None and not hasattr(v, 'is_cuda'):
+                    v = np.ascontiguousarray(v, dtype=np.float64)
+                row[name] = v
+            out.append(row)
         return out
 
     def _init(self, s, fields, coeffs):
@@ -1172,7 +1196,8 @@ class _FusedExternal3F(object):
         b._alloc_state(s, fields)
         self.fields, self.nb, self.n = fields, b.nb, b.n
         nb, n = self.nb, self.n
-        self.static = all(getattr(f.compute_all_H, 'static_H', False) is True for f in fields)
+        self.static_cb = [getattr(f.compute_all_H, 'static_H', False) is True for f in fields]
+        self.static = all(self.static_cb)
         from .ensemble import device_arrays
         self.flux = device_arrays([((nb, n), np.float64)] * 3, zero=True)
         # one device array and one page-locked staging buffer per coefficient the callbacks return, in the shape they
@@ -1188,15 +1213,22 @@ class _FusedExternal3F(object):
                 self.coef[k][name] = (H.DeviceArray(shape), H.PinnedArray(shape))
         self._upload_coeffs(coeffs)
         self._pin_in = [H.PinnedArray((nb, n)) for _ in range(3)]
-        self._pin_flux = [H.PinnedArray((nb, n)) for _ in range(3)]
+        self._pin_flux = None if self.device_model else [H.PinnedArray((nb, n)) for _ in range(3)]
 
     def _upload_coeffs(self, coeffs):
         for k, c in enumerate(coeffs):
+            if c is None:
+                continue
             if sorted(name for name, v in c.items() if v is not None) != sorted(self.coef[k]):
                 raise RuntimeError('compute_all_H of field %r returned another set of coefficients than at the start' % self.fields[k].label)
             for name, (dev, pin) in self.coef[k].items():
-                pin.array[...] = np.broadcast_to(c[name], pin.shape)
-                pin.upload(dev)
+                v = c[name]
+                if hasattr(v, 'is_cuda'):          # a CUDA tensor: device to device on torch's stream (= the library's for this run)
+                    import torch
+                    _torch_view(dev, v.device).copy_(torch.broadcast_to(v.to(torch.float64), dev.shape))
+                else:
+                    pin.array[...] = np.broadcast_to(v, pin.shape)
+                    pin.upload(dev)
 
     def params(self, s):
         b = self._base
@@ -1226,7 +1258,10 @@ class _FusedExternal3F(object):
         return out
 
     def _refresh_coeffs(self, s):
-        coeffs = self._call_callbacks(s, self.fields, self._profiles_on_host(s, self._base.u), s.t)
+        todo = [k for k in range(3) if not self.static_cb[k]]
+        on_host = any(not self.device_cb[k] for k in todo)
+        coeffs = self._call_callbacks(s, self.fields, self._profiles_on_host(s, self._base.u) if on_host else None, s.t,
+                                      getattr(self, '_dev_u', None), only=todo)
         if coeffs is None:
             raise RuntimeError('a compute_all_H callback now returns coefficients the fused three-field step does not take '
                                '(H1 other than 1, or H2, H3, H4): construct the Solver with fusedPaths=False')
@@ -1247,6 +1282,23 @@ class _FusedExternal3F(object):
         hist = s.profilesAllIterations
         done = start = b.start = s.iterationNumber
         pick = (lambda a: a) if s.batched else (lambda a: a[0])
+        previous_stream = H.stream()
+        if self.device_model or any(self.device_cb):
+            # tensors that view the solver's memory, for a flux model and callbacks that live on the GPU; the library
+            # works on torch's current stream for the duration of the timestep
+            import torch
+            dev = torch.device('cuda', torch.cuda.current_device())
+            self._dev_u = {f.label: pick(_torch_view(a, dev)) for f, a in zip(self.fields, b.u)}
+            dev_uE = {f.label: pick(_torch_view(a, dev)) for f, a in zip(self.fields, b.uE)}
+            dev_flux = [_torch_view(a, dev) for a in self.flux]
+            H.set_stream(torch.cuda.current_stream().cuda_stream)
+        try:
+            self._iterate(s, b, q, th, a_prof, inner, hist, done, start, pick, dev_uE if self.device_model else None,
+                          dev_flux if self.device_model else None)
+        finally:
+            H.set_stream(previous_stream)
+
+    def _iterate(self, s, b, q, th, a_prof, inner, hist, done, start, pick, dev_uE, dev_flux):
         while done < s.maxIterations:
             if (done - start) % s.iterationsPerCheck == 0:
                 H.check(H.lib.tg_status_reduce(b.status.ptr, self.nb, b.counts.ptr, H.stream()))
@@ -1255,15 +1307,21 @@ class _FusedExternal3F(object):
             # EWMA of the profiles that still iterate, the flux model on it (tango/lodestro_method.py:342-362)
             for k in range(3):
                 H.check(H.lib.tg_ewma_profiles(b.u[k].ptr, b.uE[k].ptr, float(a_prof), b.status.ptr, self.nb, self.n, H.stream()))
-            fluxes = th.fluxModel.get_flux(self._profiles_on_host(s, b.uE))
-            for f, pin, dev in zip(self.fields, self._pin_flux, self.flux):
-                flux = np.asarray(fluxes[f.label], dtype=np.float64)
-                if th.doSmoothing:
-                    flux = np.asarray(th.fluxSmoother.smooth(flux), dtype=np.float64)
-                if hist is not None and s.fluxesAllIterations is not None:
-                    s.fluxesAllIterations[f.label][done - start] = flux
-                pin.array[...] = np.atleast_2d(flux)
-                pin.upload(dev)
+            if dev_uE is not None:
+                import torch
+                fluxes = th.fluxModel.get_flux(dev_uE)
+                for f, view in zip(self.fields, dev_flux):
+                    view.copy_(torch.as_tensor(fluxes[f.label], device=view.device).reshape(self.nb, self.n))
+            else:
+                fluxes = th.fluxModel.get_flux(self._profiles_on_host(s, b.uE))
+                for f, pin, dev in zip(self.fields, self._pin_flux, self.flux):
+                    flux = np.asarray(fluxes[f.label], dtype=np.float64)
+                    if th.doSmoothing:
+                        flux = np.asarray(th.fluxSmoother.smooth(flux), dtype=np.float64)
+                    if hist is not None and s.fluxesAllIterations is not None:
+                        s.fluxesAllIterations[f.label][done - start] = flux
+                    pin.array[...] = np.atleast_2d(flux)
+                    pin.upload(dev)
             # the fields' own coefficients for the current profiles (tango/multifield.py:202)
             if not self.static:
                 self._refresh_coeffs(s)

@@ -473,3 +473,13 @@ def test_threefield_step_with_outside_inputs_vs_oracle(tango, N, nb):
     q.pseudo_time = 1
     with pytest.raises(NotImplementedError):
         H.check(H.lib.tg_picard_3f_step(C.byref(E.state), C.byref(q), H.stream()))
+
+
+def test_threefield_outside_inputs_on_the_device():
+    """The same with the flux model and the collision terms on the GPU (tests/device_coupled_case.py).  In a process of its
+    own: torch brings its own HIP runtime, which has to be loaded before libtango_hip.so for the two to share it."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, 'device_coupled_case.py')], capture_output=True, text=True, timeout=160)
+    assert r.returncode == 0 and 'device coupled case ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
