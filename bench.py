@@ -480,8 +480,9 @@ def main():
                                         'clock_warmup_iterations': clock_warmup,
                                         'check_every': check, 'all_reduce_rounds_in_timed_region': timed_checks,
                                         'reduced_results_consumed': mon.consumed},
-                       'parallelism': f'batch sharded over {world} GPU(s), contiguous ranges, no data exchange; RCCL all-reduce of 4 int64 '
-                                      f'counters + 5 fp64 residual summary values per check' if world > 1 else 'one GPU (no collective traffic)'},
+                       'parallelism': f'batch sharded over {world} rank(s), contiguous ranges, no data exchange; '
+                                      f'{"RCCL" if args.backend == "nccl" else args.backend} all-reduce of 4 int64 counters + 5 fp64 residual '
+                                      f'summary values per check' if world > 1 else 'one GPU (no collective traffic)'},
             'roofline': roofline,
             'convergence_summary_last_check': {k: (float(v) if v is not None else None) for k, v in red.items()},
             'invalid_profiles': bad,
