@@ -175,13 +175,9 @@ __global__ void seg_halo_kernel(tg_state_1f S_, SegWork W) {
 // x_i = (f_i - l_i y_left) - e_i x_{i+1}, from the eliminated rows that lane left in SegWork::edge: the same operations on
 // the same numbers as the owner of those rows will perform.
 // side 0: last lane of the segment on the left (row 6 is enough), 1: first lane of the segment on the right (rows 6..0).
-// The 21 doubles a boundary thread works from: side 1 the rows 0..6 (f, l, e) of the first lane of the segment on the
-// right, side 0 the last 21 doubles of the left segment's record, whose last three are row 6 of its lane 63.
-__device__ __forceinline__ const double *boundary_rows(const SegWork &W, int64_t b, int S, int k, int side) {
-    return W.edge + (int64_t)kEdgeQ * (b * S + k + side) + (side ? 0 : 3);
-}
-
-// rec: this thread's 21 doubles of boundary_rows; y_of_lane: the lane unknowns of the profile in lane order.
+// rec: the 21 doubles this thread works from: side 1 the rows 0..6 (f, l, e) of the first lane of the segment on the right,
+// side 0 the last 21 doubles of the left segment's record, whose last three are row 6 of its lane 63; y_of_lane: the lane
+// unknowns of the profile in lane order.
 __device__ __forceinline__ void boundary_finish(const tg_state_1f &S_, const SegWork &W, int64_t b, int k, int side,
                                                 const double *rec, const double *y_of_lane) {
     constexpr int P = 8;
@@ -694,14 +690,15 @@ picard_seg_reduce_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int next, in
     // the rows the segments' edge lanes left).  Everything this takes from memory is fetched here, before the first store.
     const bool edge = next && t < 2 * (S - 1);
     double bv[8];
-    double *rec = lds + 8 * G::T + rows + 21 * t;      // behind the exchange area and the lane unknowns: 21 doubles per boundary thread
-    if (edge) {
-        if ((t & 1) == 0) boundary_values(S_, b, t >> 1, bv);
-        // the rows wait in LDS, not in registers, while the reduced system is solved
-        const double *src = boundary_rows(W, b, S, t >> 1, t & 1);
-#pragma unroll
-        for (int i = 0; i < 21; ++i) rec[i] = src[i];
+    // the records of the profile's segments (SegWork::edge) wait in LDS, behind the exchange area and the lane unknowns, while
+    // the reduced system is solved: fetched by the whole workgroup, coalesced
+    double *recs = lds + 8 * G::T + rows;
+    if (next) {
+        const double *src = W.edge + (int64_t)kEdgeQ * (b * S);
+        for (int i = t; i < kEdgeQ * S; i += G::T) recs[i] = src[i];
     }
+    const double *rec = recs + kEdgeQ * ((t >> 1) + (t & 1)) + ((t & 1) ? 0 : 3);
+    if (edge && (t & 1) == 0) boundary_values(S_, b, t >> 1, bv);
     double seg_ss = 0.0, seg_mx = 0.0;      // residual partial sums of the segments
     int it0 = 0;
     if (t == 0) {
@@ -815,8 +812,8 @@ int tg_seg_step(const tg_state_1f *st, const tg_params_1f *q, hipStream_t s) {
     const int lanes = n / 64;      // threads of the reduce kernel: 8 reduced rows each
     const size_t lds_r = sizeof(double) * 8 * (size_t)lanes;
     if (lanes != 64 && lanes != 128 && lanes != 256 && lanes != 512) return fail(TG_ERR_UNSUPPORTED, "segmented form: n must be 4096, 8192, 16384 or 32768%s");
-    // + the lane unknowns of the profile + the rows of the boundary threads
-    const size_t lds_n = lds_r + sizeof(double) * (size_t)(n / 8) + sizeof(double) * 21 * 2 * (size_t)(n / kSeg - 1);
+    // + the lane unknowns of the profile + the records of its segments' edge lanes
+    const size_t lds_n = lds_r + sizeof(double) * (size_t)(n / 8) + sizeof(double) * kEdgeQ * (size_t)(n / kSeg);
     if (q->iters_per_launch > 1 && !q->pseudo_time && lds_n > 64 * 1024) {
         // the longest profiles: the reduce kernel's LDS goes beyond what a launch may use without asking
         if (lds_n > max_lds_bytes()) return fail(TG_ERR_UNSUPPORTED, "segmented form: not enough LDS for several iterations per call at this profile length%s");
