@@ -1119,7 +1119,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                 const double p = ue[i];
                 const double dpdx = ddx_edge1_point<EXACT>(pm, p, pp, first, last, rc);
                 double D, c;
-                if constexpr (GENERAL || EXACT) {
+                if constexpr (GENERAL) {
                     // flux model (tango/extras/shestakov_nonlinear_diffusion.py:59-60)
                     double flux = quot<DIV>(-(dpdx * dpdx * dpdx), p * p);
                     double gx = 1.0, gr = 1.0;
@@ -1131,7 +1131,10 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                     double DH, cH, thv;
                     flux_split_point<DIV>(flux, p, dpdx, gx, gr, th, D, c, DH, cH, thv);
                 } else {
-                    shestakov_split_point(p, dpdx, th, D, c);   // built-in flux, Cartesian: one quotient
+                    // built-in flux, Cartesian: one quotient.  Also on the grids of more than 512 points: DHat and cHat are
+                    // within a few ulp of the three-division values and nothing downstream amplifies that (the pivots and
+                    // the rows, where those grids' condition numbers bite, keep their correctly rounded quotients)
+                    shestakov_split_point(p, dpdx, th, D, c);
                 }
                 if constexpr (INPLACE) {
                     const double nD = Q.a_turb * D + omt * (seeded ? DE[i] : D);

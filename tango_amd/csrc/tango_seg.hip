@@ -58,6 +58,7 @@ struct SegWork {
     double *edge;         // (nb S, 24): the eliminated rows 0..6 of lane 0 of every segment (f, l, e: 21 values) and row 6 of
                           // its lane 63 (f, l, e), left by a first half; from them and the lane unknowns the reduce kernel
                           // forms the new profile next to the segment boundaries between two iterations of one call
+    int32_t *weigh;       // (nb S,) the segment's first half found a face that needs an upwinding quotient: its second half need not look again
     int32_t *flag;        // (nb,) 0: not stepped in this iteration, 1: stepped, 2: stepped and converged
     int32_t *sing;        // (nb,) zero pivot met somewhere
     // pseudo-timestep control
@@ -74,7 +75,7 @@ size_t seg_work_bytes_tread(int64_t nb, int64_t n) { return seg_work_bytes(nb, n
 size_t seg_work_bytes(int64_t nb, int64_t n) {
     const int64_t L = nb * n / 8, S = n / kSeg;
     size_t b = sizeof(double) * (size_t)((kRowQ + 1) * L + (5 + kEdgeQ) * nb * S + kHaloQ * nb * (S - 1)) + sizeof(double) * (size_t)nb +
-               sizeof(int32_t) * (size_t)(4 * nb + 4);
+               sizeof(int32_t) * (size_t)(4 * nb + 4 + nb * S);
     return (b + 255) & ~(size_t)255;
 }
 
@@ -95,6 +96,7 @@ SegWork seg_carve(void *work, int64_t nb, int64_t n) {
     W.redo = W.sing + nb;
     W.attempts = W.redo + nb;
     W.nredo = W.attempts + nb;
+    W.weigh = W.nredo + 4;
     W.uprev = reinterpret_cast<double *>(static_cast<char *>(work) + seg_work_bytes(nb, n));
     return W;
 }
@@ -129,6 +131,12 @@ __device__ __forceinline__ void seg_row(FaceCarry &c, double h2n, double h3n, bo
     c.h2c = h2n;
     c.h3c = h3n;
 }
+
+// a y + (1 - a) memory (tango/lodestro_method.py:706-711) with its rounding spelled out: one product rounded, the other
+// fused into the sum.  An edge lane computes the memories of its halo point as the neighbouring wavefront computes them for
+// itself, in another place of the code or in another kernel of the chain, and the two must agree to the bit: left as
+// a * y + om * mem the compiler fuses whichever product it likes, not the same one everywhere.
+__device__ __forceinline__ double ewma(double a, double y, double om, double mem) { return __builtin_fma(a, y, om * mem); }
 
 // One step of the back substitution inside a lane, x_i = (f_i - l_i y_left) - e_i x_{i+1}.
 __device__ __forceinline__ double back_step(double f, double l, double e, double y_left, double x_next) {
@@ -292,7 +300,8 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
     // assembly and elimination of this lane's rows (tango/HToMatrixFD.py:87-117 row by row, as in picard_1f_kernel);
     // RESID: the residual of the current profile with the new matrix (tango/fieldgroups.py:139), zero-padded shifts at
     // the two ends of the profile
-    auto assemble = [&](auto resid, ChunkElim<P, kDivRounded> &el, double &ss, double &mx) {
+    // `known`: < 0: look at the faces; 0 / 1: the first half of this iteration has (same memories, same faces) and left its answer
+    auto assemble = [&](auto resid, ChunkElim<P, kDivRounded> &el, double &ss, double &mx, int known) -> bool {
         constexpr bool RESID = decltype(resid)::value;
         // H2 = D, H3 = -c of the neighbouring lanes' nearest points; across a segment boundary the halo point's
         // (every lane takes part in the shuffles; the edge lanes then substitute their halo values)
@@ -312,8 +321,9 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         // in its operands).  When that holds at every face this wavefront uses, the quotients are skipped (a branch the whole
         // wavefront takes or not); weights and rows are the same numbers either way.  The face left of the profile's first
         // point carries H2 = H3 = 0 and its weight multiplies zeros; the Dirichlet row does not use its right face.
-        bool half = true;
-        {
+        bool weigh = known != 0;
+        if (known < 0) {       // (uniform over the wavefront)
+            bool half = true;
             // (plain & and |: evaluated for every face, no branch per face)
             auto dominated = [&](double h2, double h3) { return weight_is_moot(h2, h3, rc.dx); };
             if (!first_lane) half = dominated((h2l + DE[0]) / 2.0, (h3l - cE[0]) / 2.0);
@@ -327,8 +337,8 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
                 a2 = n2;
                 a3 = n3;
             }
+            weigh = !__all(half);
         }
-        const bool weigh = !__all(half);
         FaceCarry c;
         c.hm2 = first_lane ? 0.0 : (h2l + DE[0]) / 2.0;
         c.hm3 = first_lane ? 0.0 : (h3l - cE[0]) / 2.0;
@@ -356,6 +366,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
             }
             el.push(i, C, B, A, f);
         }
+        return weigh;
     };
 
     if (PHASE != 0) {
@@ -368,6 +379,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
         // this lane's last unknown and its left neighbour's (any segment), for the back substitution
         const double y = (W.y + lane_base)[lane_off];
         const double yl = first_lane ? 0.0 : (W.y + lane_base)[((lane_r - 1) & 7) * (n / 64) + ((lane_r - 1) >> 3)];
+        const int weigh_known = __builtin_amdgcn_readfirstlane(W.weigh[b * S + s]);      // left by this iteration's first half
         int sing0 = 0, it_old = 0;
         if (s == 0) {
             sing0 = __builtin_amdgcn_readfirstlane(W.sing[b]);
@@ -414,7 +426,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
 
         ChunkElim<P, kDivRounded> el;
         double mx = 0.0, ss = 0.0;
-        assemble(std::false_type{}, el, ss, mx);
+        assemble(std::false_type{}, el, ss, mx, weigh_known);
         // back substitution
         double x[P];
         x[P - 1] = y;
@@ -493,24 +505,26 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
             Tile::sync();
         }
 
+        // flux model and split (tango/extras/shestakov_nonlinear_diffusion.py:59-60, tango/lodestro_method.py:624-634) through
+        // the one quotient (dp/dx)/p, as in the wave-per-profile kernel: DHat and cHat are within a few ulp of the three-division
+        // values, and nothing downstream amplifies that (the pivots and the rows, where these grids' condition numbers bite,
+        // keep their correctly rounded quotients)
         auto split = [&](double pm, double p, double pp, bool first, bool last, double &D, double &c) {
             const double dpdx = ddx_edge1_point<EXACT>(pm, p, pp, first, last, rc);
-            const double flux = quot<kDivRounded>(-(dpdx * dpdx * dpdx), p * p);   // tango/extras/shestakov_nonlinear_diffusion.py:59-60
-            double DH, cH, thv;
-            flux_split_point<kDivRounded>(flux, p, dpdx, 1.0, 1.0, th, D, c, DH, cH, thv);
+            shestakov_split_point(p, dpdx, th, D, c);
         };
         if (turb) {
 #pragma unroll
-            for (int i = 0; i < P; ++i) ue[i] = Q.a_prof * u[i + 1] + omp * (seeded ? ue[i] : u[i + 1]);
-            const double e0 = Q.a_prof * n_u0 + omp * (seeded ? n_e0 : n_u0);
-            const double e1 = Q.a_prof * n_u1 + omp * (seeded ? n_e1 : n_u1);
+            for (int i = 0; i < P; ++i) ue[i] = ewma(Q.a_prof, u[i + 1], omp, seeded ? ue[i] : u[i + 1]);
+            const double e0 = ewma(Q.a_prof, n_u0, omp, seeded ? n_e0 : n_u0);
+            const double e1 = ewma(Q.a_prof, n_u1, omp, seeded ? n_e1 : n_u1);
             h_ue = e0;
             // D and c at the halo point, from the new EWMA profile on both of its sides
             {
                 double D, c;
                 split(edge_l ? e1 : ue[P - 1], e0, edge_l ? ue[0] : e1, false, false, D, c);
-                h_D = Q.a_turb * D + omt * (seeded ? n_D : D);
-                h_c = Q.a_turb * c + omt * (seeded ? n_c : c);
+                h_D = ewma(Q.a_turb, D, omt, seeded ? n_D : D);
+                h_c = ewma(Q.a_turb, c, omt, seeded ? n_c : c);
             }
             double wl = g.from_left(ue[P - 1], 1, 0.0);
             double wr = g.from_right(ue[0], 1, 0.0);
@@ -524,8 +538,8 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
                 const double pp = (i == P - 1) ? wr : ue[i < P - 1 ? i + 1 : 0];
                 double D, c;
                 split(pm, ue[i], pp, first, last, D, c);
-                DE[i] = Q.a_turb * D + omt * (seeded ? DE[i] : D);
-                cE[i] = Q.a_turb * c + omt * (seeded ? cE[i] : c);
+                DE[i] = ewma(Q.a_turb, D, omt, seeded ? DE[i] : D);
+                cE[i] = ewma(Q.a_turb, c, omt, seeded ? cE[i] : c);
             }
             wt.put(0, ue);
             wt.put(1, DE);
@@ -546,7 +560,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
 
         ChunkElim<P, kDivRounded> el;
         double mx = 0.0, ss = 0.0;
-        assemble(std::true_type{}, el, ss, mx);
+        const bool weighed = assemble(std::true_type{}, el, ss, mx, -1);
 
         // The eliminated rows the neighbouring segments' wavefronts will want between this iteration and the next one of the
         // same call (see SegWork::edge): rows 0..6 of lane 0 and row 6 of lane 63.  They go through a 24-double record in LDS
@@ -611,6 +625,7 @@ picard_seg_kernel(tg_state_1f S_, tg_params_1f Q, SegWork W, int mode) {
             Fq[2] = tau;
             W.ss[b * S + s] = ss;
             W.mx[b * S + s] = mx;
+            W.weigh[b * S + s] = weighed ? 1 : 0;
             if (sing) atomicOr(&W.sing[b], 1);
         }
     }
