@@ -31,7 +31,7 @@ extern "C" {
 typedef void *tg_stream;
 
 enum { TG_OK = 0, TG_ERR_ARG = 1, TG_ERR_HIP = 2, TG_ERR_UNSUPPORTED = 3 };
-enum { TG_POINT_FASTEST = 0, TG_BATCH_FASTEST = 1 };
+enum { TG_POINT_FASTEST = 0, TG_BATCH_FASTEST = 1, TG_BATCH_FASTEST_TILED = 2 /* tg_tridiag_solve only: see there */ };
 
 /* per-profile status bits written by the solvers */
 enum {
@@ -78,7 +78,11 @@ int tg_stream_probe(const double *const in[5], double *const out[4], int64_t cou
  *  - batch-fastest: one lane per profile performing LAPACK dgtsv's sweeps operation by operation, row
  *    interchanges included, without floating-point contraction: bit-identical to the reference's result.  Needs
  *    tg_tridiag_work_bytes() of work space (pivots, modified super-diagonal, second super-diagonal).  u may
- *    alias D but not A, B or C.
+ *    alias D but not A, B or C;
+ *  - TG_BATCH_FASTEST_TILED: the same interleaved arrays X[j*nb + b], solved by the point-fastest algorithm (a
+ *    workgroup moves 16 neighbouring profiles through LDS, a wavefront each): the results of TG_POINT_FASTEST
+ *    on the transposed arrays (bit for bit for 256 < n <= 512, where both give a profile a whole wavefront), 40 bytes of memory traffic per point instead of 80; n <= 512; no work
+ *    space; u may alias any input.
  * status: optional (nb,) int32, TG_ST_SINGULAR is OR-ed in for a profile that met a zero pivot. */
 size_t tg_tridiag_work_bytes(int64_t nb, int64_t n, int layout);
 int tg_tridiag_solve(const double *A, const double *B, const double *C, const double *D, double *u,

@@ -7,10 +7,11 @@ from tango_amd import _hip as H
 import bench_configs as B
 H.set_stream(torch.cuda.current_stream().cuda_stream)
 st = H.stream()
-nb, n = 65536, 512
+nb, n = int(os.environ.get('TG_NB', 65536)), 512
 rng = np.random.default_rng(0)
 a = -rng.uniform(0.5, 1, (nb, n)); c = -rng.uniform(0.5, 1, (nb, n)); b = 2.5 + rng.uniform(0, 1, (nb, n)); d = rng.standard_normal((nb, n))
-for layout, name in ((0, 'point-fastest (wave per profile, chunked elimination + PCR)'), (1, 'batch-fastest (lane per profile, dgtsv sweeps)')):
+for layout, name in ((0, 'point-fastest (wave per profile, chunked elimination + PCR)'), (1, 'batch-fastest (lane per profile, dgtsv sweeps)'),
+                     (2, 'batch-fastest, tiles of 16 profiles through LDS, chunked elimination + PCR')):
     arrs = [H.DeviceArray.from_host(v if layout == 0 else np.ascontiguousarray(v.T)) for v in (a, b, c, d)]
     u = H.DeviceArray((nb, n)); status = H.DeviceArray((nb,), np.int32, zero=True)
     wb = H.lib.tg_tridiag_work_bytes(nb, n, layout)

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TANGO_HIP_LIB') or os.path.join(_HERE, 'lib', 'libtango_hip.so')
 
 TG_OK, TG_ERR_ARG, TG_ERR_HIP, TG_ERR_UNSUPPORTED = 0, 1, 2, 3
-POINT_FASTEST, BATCH_FASTEST = 0, 1
+POINT_FASTEST, BATCH_FASTEST, BATCH_FASTEST_TILED = 0, 1, 2
 ST_CONVERGED, ST_INVALID, ST_SINGULAR, ST_SEEDED, ST_TREAD_LIMIT = 1, 2, 4, 8, 16
 FLUX_SHESTAKOV, FLUX_EXTERNAL, FLUX_POWER = 0, 1, 2
 STATIC_WORK_BYTES = 24 * 1024 * 1024

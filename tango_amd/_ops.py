@@ -101,9 +101,10 @@ def _raise_singular(status):
 
 
 def tridiag_solve(A, B, Cc, D, layout=H.POINT_FASTEST, check_singular=True):
-    """tango/tridiag.py:12-31.  With layout=BATCH_FASTEST the (device) arrays are (N, profiles)."""
+    """tango/tridiag.py:12-31.  With layout=BATCH_FASTEST (dgtsv's sweeps, any N) or BATCH_FASTEST_TILED (the
+    point-fastest algorithm on interleaved arrays, N <= 512) the (device) arrays are (N, profiles)."""
     cx = _Ctx()
-    if layout == H.BATCH_FASTEST:
+    if layout in (H.BATCH_FASTEST, H.BATCH_FASTEST_TILED):
         if not all(H.is_device(v) for v in (A, B, Cc, D)):
             raise AssertionError('batch-fastest layout takes device arrays of shape (N, profiles)')
         n, nb = A.shape

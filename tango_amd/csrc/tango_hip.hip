@@ -252,6 +252,91 @@ tridiag_bf_kernel(const double *__restrict__ A, const double *__restrict__ B, co
     if (status && info) atomicOr(&status[b], TG_ST_SINGULAR);
 }
 
+// Tridiagonal solve, batch-fastest arrays, solved by the point-fastest algorithm (n <= 512).
+//
+// A workgroup of W = 16 wavefronts takes 16 neighbouring profiles: in the interleaved layout their entries of one row
+// are a whole 128-byte line, and a wavefront instruction moves four such rows.  Thread 64 w + l of pass r holds element
+// (row 64 r + 4 w + l/16, profile l%16).  The rows go through 16 LDS tiles, one per profile, in the layout of
+// tg_wave_io.h (tile bases 16 bytes apart modulo the bank period); wavefront w then takes profile w out of its tile,
+// eight consecutive points per lane, and solves it exactly as tridiag_pf_kernel does: the results are that kernel's
+// bit for bit.  40 bytes per point, against 80 for the dgtsv sweeps above, which have to park the pivots and the
+// modified right-hand side in memory between the two sweeps.  What bounds it is the access shape, not the solve: a
+// workgroup reads a strip one line wide and 512 rows tall, rows a whole batch apart (the same kernel without the
+// solve takes as long), and the two tile buffers of 16 profiles leave room for one workgroup per CU.  Measured at
+// 65 536 x 512: 0.355 ms; with W = 8 (64-byte pieces of a row, two workgroups per CU) 0.645 ms, 0.443 ms when the two
+// workgroups that share a line are sent to the same XCD at the same time.  It is the faster way to solve arrays that
+// ARE interleaved; arrays that can be laid out either way belong in the point-fastest layout.
+constexpr int kTileStride = 512 + 2;     // doubles between the tiles of neighbouring profiles
+template <int W, bool FULL>      // W = 8 or 16 profiles per workgroup, a wavefront each; W = 16 is the one launched
+__global__ void __launch_bounds__(64 * W, 4)
+tridiag_bt_kernel(const double *__restrict__ A, const double *__restrict__ B, const double *__restrict__ C,
+                  const double *D, double *u, int64_t nb, int n, int32_t *__restrict__ status) {
+    extern __shared__ double lds[];
+    using G = WaveGroup<64>;
+    using Tile = WaveTile<8>;
+    G g(lds);
+    const int lane = threadIdx.x & 63, w = wave_in_block();
+    const int64_t b0 = (int64_t)blockIdx.x * W;
+    // the element this thread moves in pass r: row 64 r + jrow, profile b0 + p
+    const int p = lane & (W - 1), jrow = (64 / W) * w + lane / W;
+    const bool pin = FULL || b0 + p < nb;
+    // ... and its place in tile p: piece (64 r + jrow) / 2 = 64 (r/2) + 4 a + k with a = 8 (r%2) + jrow/8, k = (jrow/2)%4
+    const int k = (jrow >> 1) & 3, xk = Tile::X(k), a0 = jrow >> 3;
+    const int place0 = p * kTileStride + 2 * (16 * k + (a0 ^ xk)) + (jrow & 1);
+    const int place1 = p * kTileStride + 2 * (16 * k + ((8 + a0) ^ xk)) + (jrow & 1);
+    auto place = [&](int r) { return ((r & 1) ? place1 : place0) + 128 * (r >> 1); };
+    auto fetch = [&](const double *X, double (&v)[8], double fill) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int j = 64 * r + jrow;
+            v[r] = (FULL || (pin && j < n)) ? __builtin_nontemporal_load(&X[(int64_t)j * nb + b0 + p]) : fill;
+        }
+    };
+    auto stage = [&](int buf, const double (&v)[8]) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) lds[buf * W * kTileStride + place(r)] = v[r];
+    };
+    double r0[8], r1[8], r2[8], r3[8];
+    fetch(A, r0, 0.0);
+    fetch(B, r1, 1.0);
+    fetch(C, r2, 0.0);
+    fetch(D, r3, 0.0);
+    Tile t0(lds + w * kTileStride), t1(lds + (W + w) * kTileStride);
+    double a[8], bb[8], c[8], d[8];
+    stage(0, r0);
+    stage(1, r1);
+    __syncthreads();
+    t0.take(0, a);
+    t1.take(0, bb);
+    __syncthreads();
+    stage(0, r2);
+    stage(1, r3);
+    __syncthreads();
+    t0.take(0, c);
+    t1.take(0, d);
+    const int j0 = 8 * lane;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c[i] = (j0 + i == 0) ? 0.0 : c[i];
+        a[i] = (j0 + i == n - 1) ? 0.0 : a[i];
+    }
+    int sing = 0;
+    chunk_solve<8>(g, c, bb, a, d, sing);
+    Tile::sync();          // the wavefront's own reads of tile w are done: the tile takes the solution
+    t0.put(0, d);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int j = 64 * r + jrow;
+        const double x = lds[place(r)];
+        if (FULL || (pin && j < n)) __builtin_nontemporal_store(x, &u[(int64_t)j * nb + b0 + p]);
+    }
+    if (status) {
+        sing = g.any2(sing);
+        if (sing && lane == 0 && (FULL || b0 + w < nb)) atomicOr(&status[b0 + w], TG_ST_SINGULAR);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Element-wise / stencil kernels on (nb, n) point-fastest arrays: one thread per point.
 // ------------------------------------------------------------------------------------------
@@ -1608,6 +1693,21 @@ int tg_tridiag_solve(const double *A, const double *B, const double *C, const do
         double *wd = (double *)work, *wdu = wd + nb * n, *wdu2 = wdu + nb * n;
         hipLaunchKernelGGL(tridiag_bf_kernel<8>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, S(stream), A, B, C, D, u, nb,
                            (int)n, wd, wdu, wdu2, status);
+        return launch_check();
+    }
+    if (layout == TG_BATCH_FASTEST_TILED) {
+        if (n > 512) return fail(TG_ERR_UNSUPPORTED, "TG_BATCH_FASTEST_TILED takes grids of up to 512 points (TG_BATCH_FASTEST has no limit)%s");
+        constexpr int W = 16;
+        const size_t lds = sizeof(double) * 2 * W * kTileStride;      // beyond 64 KiB: has to be asked for
+        if (lds > max_lds_bytes()) return fail(TG_ERR_UNSUPPORTED, "not enough LDS on this device%s");
+        const unsigned grid = (unsigned)((nb + W - 1) / W);
+        if (n == 512 && nb % W == 0) {
+            TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tridiag_bt_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((tridiag_bt_kernel<W, true>), dim3(grid), dim3(64 * W), lds, S(stream), A, B, C, D, u, nb, (int)n, status);
+        } else {
+            TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tridiag_bt_kernel<W, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((tridiag_bt_kernel<W, false>), dim3(grid), dim3(64 * W), lds, S(stream), A, B, C, D, u, nb, (int)n, status);
+        }
         return launch_check();
     }
     if (layout != TG_POINT_FASTEST) return fail(TG_ERR_ARG, "unknown layout%s");

@@ -7,7 +7,10 @@ reference routes it to LAPACK dgtsv through SciPy (:88-97) and also ships a pure
                       (N,) or (profiles, N), host or device): the fast path, within rounding of the reference;
   `solve_with_scipy`  the lane-per-profile kernel on the interleaved batch-fastest layout, which performs dgtsv's
                       sweeps operation by operation (partial pivoting included): the reference's result bit for bit;
-  `solve_python`      the same kernel behind the reference's asserts on A[-1] and C[0]."""
+  `solve_python`      the same kernel behind the reference's asserts on A[-1] and C[0];
+  `solve_interleaved` device arrays of shape (N, profiles), i.e. the interleaved batch-fastest layout: `exact=True` the
+                      dgtsv kernel, `exact=False` (N <= 512) the fast path's algorithm on tiles of 16 profiles
+                      transposed through LDS, its results bit for bit at half the memory traffic."""
 import numpy as np
 
 from . import _hip as H
@@ -16,6 +19,11 @@ from . import _ops
 
 def solve(A, B, C, D):
     return _ops.tridiag_solve(A, B, C, D)
+
+
+def solve_interleaved(A, B, C, D, exact=False):
+    """Device arrays (N, profiles) in, device array (N, profiles) out."""
+    return _ops.tridiag_solve(A, B, C, D, layout=H.BATCH_FASTEST if exact else H.BATCH_FASTEST_TILED)
 
 
 def _solve_batch_fastest(A, B, C, D):

@@ -52,6 +52,47 @@ def test_tridiag_sizes_batched(tango, n):
     assert np.array_equal(u, ref)       # the reference's LAPACK sweeps operation by operation
 
 
+@pytest.mark.parametrize('n,nb', [(1, 3), (2, 8), (7, 9), (64, 5), (255, 16), (257, 7), (500, 13), (512, 8), (512, 16), (512, 48), (512, 37)])
+def test_tridiag_interleaved_tiled(tango, golden, n, nb):
+    """Interleaved (N, profiles) arrays solved by the point-fastest algorithm on tiles of 16 profiles: the oracle's
+    result to 1e-12, and the point-fastest entry's bit for bit where that one gives a profile a whole wavefront too."""
+    from tango_amd import _ops, _hip
+    rng = np.random.default_rng(1000 * n + nb)
+    A = rng.uniform(-1, 1, (nb, n)); C = rng.uniform(-1, 1, (nb, n))
+    B = (np.abs(A) + np.abs(C) + rng.uniform(0.05, 1, (nb, n))) * rng.choice([-1.0, 1.0], (nb, 1))
+    D = rng.normal(size=(nb, n))
+    A[:, -1] = 7.0; C[:, 0] = -3.0
+    if n == 500:                             # the reference's own 500-point system among them
+        g = golden('g1_tridiag')
+        A[0], B[0], C[0], D[0] = (g[f'r500_{k}'] for k in 'ABCD')
+    ref = orc.tridiag_solve(A, B, C, D)
+    dev = [tango.DeviceArray.from_host(np.ascontiguousarray(v.T)) for v in (A, B, C, D)]
+    keep = [d.to_host() for d in dev]
+    u = tango.tridiag.solve_interleaved(*dev).to_host()
+    assert u.shape == (n, nb)
+    bar = 1e-12 if n != 500 else 1e-11       # r500 needs row interchanges in LAPACK: not diagonally dominant
+    assert relerr(u.T, ref) < bar
+    assert all(np.array_equal(k, d.to_host()) for k, d in zip(keep, dev))
+    if n > 256:
+        assert np.array_equal(u.T, tango.tridiag.solve(A, B, C, D))
+    # the exact variant on the same arrays, and the solution written over the right-hand side
+    assert np.array_equal(tango.tridiag.solve_interleaved(*dev, exact=True).to_host().T, ref)
+    status = tango.DeviceArray((nb,), np.int32, zero=True)
+    _hip.check(_hip.lib.tg_tridiag_solve(dev[0].ptr, dev[1].ptr, dev[2].ptr, dev[3].ptr, dev[3].ptr, nb, n, _hip.BATCH_FASTEST_TILED,
+                                         status.ptr, None, 0, _hip.stream()))
+    assert np.array_equal(dev[3].to_host(), u) and not status.to_host().any()
+
+
+def test_tridiag_interleaved_tiled_errors(tango):
+    from tango_amd import _hip
+    z = [tango.DeviceArray.from_host(np.zeros((3, 9))) for _ in range(3)] + [tango.DeviceArray.from_host(np.ones((3, 9)))]
+    with pytest.raises(np.linalg.LinAlgError):
+        tango.tridiag.solve_interleaved(*z)
+    big = [tango.DeviceArray.from_host(np.ones((513, 2))) for _ in range(4)]
+    with pytest.raises(NotImplementedError):
+        tango.tridiag.solve_interleaved(*big)
+
+
 def test_tridiag_inputs_untouched_and_errors(tango):
     A = np.array([0.1, 0.1, 0.0]); B = np.array([1.0, 1.0, 1.0]); C = np.array([0.0, 0.1, 0.1]); D = np.array([1.0, 2.0, 3.0])
     keep = [v.copy() for v in (A, B, C, D)]
