@@ -94,34 +94,46 @@ block3_solve_kernel(const double *__restrict__ Cb, const double *__restrict__ Bb
     if (b >= nb) return;
     const int j0 = g.t() * P;
     const int64_t plane = nb * (int64_t)n, off = b * (int64_t)n;
+    // every plane's P points of this lane in one piece (16-byte loads where the row allows them; element by element the
+    // kernel took 0.93 ms at 16 384 x 512, so 0.64; two points per lane, three wavefronts' worth of registers less
+    // and fully coalesced, but twice the cyclic-reduction work per point: 0.78 ms)
+    constexpr bool STREAM = false;
+    double cb[9][P], bk[9][P], ab[9][P], dd[3][P];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        load_chunk<P, false, STREAM>(Cb + k * plane + off, n, j0, cb[k], 0.0);
+        load_chunk<P, false, STREAM>(Bb + k * plane + off, n, j0, bk[k], (k % 4 == 0) ? 1.0 : 0.0);
+        load_chunk<P, false, STREAM>(Ab + k * plane + off, n, j0, ab[k], 0.0);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) load_chunk<P, false, STREAM>(d + r * plane + off, n, j0, dd[r], 0.0);
     BlockElim<3, P> el;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int j = j0 + i;
         Mat<3> Cm, Bm, Am;
         Vec<3> dv;
-        const bool valid = j < n;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const int64_t k = (r * 3 + c) * plane + off + (valid ? j : 0);
-                Cm.m[r][c] = (valid && j > 0) ? Cb[k] : 0.0;
-                Am.m[r][c] = (valid && j < n - 1) ? Ab[k] : 0.0;
-                Bm.m[r][c] = valid ? Bb[k] : (r == c ? 1.0 : 0.0);
+                Cm.m[r][c] = (j > 0) ? cb[r * 3 + c][i] : 0.0;
+                Am.m[r][c] = (j < n - 1) ? ab[r * 3 + c][i] : 0.0;
+                Bm.m[r][c] = bk[r * 3 + c][i];
             }
-            dv.v[r] = valid ? d[r * plane + off + j] : 0.0;
+            dv.v[r] = dd[r][i];
         }
         el.push(i, Cm, Bm, Am, dv);
     }
     Vec<3> xs[P];
     el.finish(g, xs);
 #pragma unroll
-    for (int i = 0; i < P; ++i)
-        if (j0 + i < n) {
+    for (int r = 0; r < 3; ++r) {
+        double xr[P];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) x[r * plane + off + j0 + i] = xs[i].v[r];
-        }
+        for (int i = 0; i < P; ++i) xr[i] = xs[i].v[r];
+        store_chunk<P, false, STREAM>(x + r * plane + off, n, j0, xr);
+    }
     if (status) {
         const int sing = g.any2(el.singular);
         if (sing && g.t() == 0) atomicOr(&status[b], TG_ST_SINGULAR);
