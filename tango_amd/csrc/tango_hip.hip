@@ -1094,6 +1094,15 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             landed(src_row[i]);
         }
     }
+    // A profile's first iterate seeds the EWMA memory of the profile (tango/lodestro_method.py:706-708): where a wavefront
+    // owns the profile that is a copy made here, once, instead of a select in every iteration of the launch
+    constexpr bool PRESEED = !G::kBlock && G::T == 64;
+    if constexpr (PRESEED) {
+        if (!(st & TG_ST_SEEDED) && !Q.frozen_turb && !external) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) ue[i] = u[i + 1];
+        }
+    }
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) {
         if constexpr (!MULTI && !PACKED) done = false;
@@ -1122,7 +1131,7 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
                         const double v = Q.a_prof * u[i + 1] + omp * (seeded ? ue[i] : u[i + 1]);
                         ue[i] = hold ? ue[i] : v;
                     }
-                } else if (seeded) {
+                } else if (PRESEED || seeded) {
 #pragma unroll
                     for (int i = 0; i < P; ++i) ue[i] = Q.a_prof * u[i + 1] + omp * ue[i];
                 } else {     // the first iterate seeds the memory (tango/lodestro_method.py:706-708)

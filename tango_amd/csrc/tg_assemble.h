@@ -51,12 +51,23 @@ __device__ __forceinline__ double theta_point(double dh, double dpdx, const Thet
     double qm;
     if constexpr (FAST == kDivIeee) qm = (th.Dmax - dh) / th.span;
     else qm = quot_by(th.Dmax - dh, th.span, th.ispan);
-    const double mid = (1.0 + qm) / 2.0;
-    double tv = 1.0;
-    tv = (dh < th.Dmin) ? 0.0 : tv;
-    tv = (small && dh >= th.Dmin && dh <= th.Dmax) ? mid : tv;
-    tv = (small && dh > th.Dmax) ? 0.5 : tv;
-    return tv;
+    if constexpr (FAST == kDivIeee) {
+        const double mid = (1.0 + qm) / 2.0;
+        double tv = 1.0;
+        tv = (dh < th.Dmin) ? 0.0 : tv;
+        tv = (small && dh >= th.Dmin && dh <= th.Dmax) ? mid : tv;
+        tv = (small && dh > th.Dmax) ? 0.5 : tv;
+        return tv;
+    } else {
+        // The same values from two comparisons and two selects instead of five and three (the fused kernels evaluate this
+        // at every point of every iteration): beyond Dmax the quotient is negative and (1 + max(q, 0)) / 2 is the 1/2
+        // wanted there, at Dmax and below the maximum changes nothing.  A NaN DHat gives 1/2 here where the rule above
+        // gives 1; theta itself is not an output of the fused kernels, D = theta DHat is NaN either way, and a profile
+        // with a NaN coefficient is reported invalid whatever its c.
+        const double mid = (1.0 + fmax(qm, 0.0)) / 2.0;
+        const double in = small ? mid : 1.0;
+        return (dh < th.Dmin) ? 0.0 : in;
+    }
 }
 
 // tango/lodestro_method.py:624-634 (DHat, cHat, D, c).
@@ -116,9 +127,11 @@ __device__ __forceinline__ double fbeta_point(double H2h, double H3h, double dx)
 //  - H3 == 0 (no convective part at this face: theta = 1 everywhere, as with the example scripts' thetaParams): fbeta gives
 //    0 there, but the weight only ever multiplies H3 (fd_row), and a zero times any finite non-negative weight is the same
 //    zero, sign included.
-// NaN operands compare false: such a face takes the quotient, as before.  Plain & and |: no branch per face.
+// One comparison covers both: H2 is never negative (a diffusivity times positive geometry factors), so H3 == 0 passes
+// H2 >= 0 as well; and |H3 (dx/2)| is |H3 dx| / 2 to the bit (a power of two scales exactly).  NaN operands compare false:
+// such a face takes the quotient, which gives the same row (and so would a negative H2 at a face with H3 = 0).
 __device__ __forceinline__ bool weight_is_moot(double h2, double h3, double dx) {
-    return bool((h3 == 0.0) | (h2 >= 0.5 * fabs(h3 * dx)));
+    return h2 >= fabs(h3 * (0.5 * dx));
 }
 
 // tango/derivatives.py:20-24: centred difference with two-point one-sided ends.
