@@ -18,6 +18,16 @@ lines = []
 for f in find('trace', '*kernel_stats.csv'):
     for r in csv.DictReader(open(f)):
         lines.append(f"STATS {r.get('Name','')[:110]:110s} calls={r.get('Calls')} avg_ns={r.get('AverageNs')} total_ns={r.get('TotalDurationNs')} pct={r.get('Percentage')}")
+# median duration per kernel from the trace itself: the average above includes the launches that run while the clock is
+# still coming up (the first few of a run take up to 25 % longer), the median is the steady launch
+dur = collections.defaultdict(list)
+for f in find('trace', '*kernel_trace.csv'):
+    for r in csv.DictReader(open(f)):
+        if any(w in r['Kernel_Name'] for w in KEEP):
+            dur[r['Kernel_Name'][:110]].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+for k, v in dur.items():
+    v.sort()
+    lines.append(f"MEDIAN {k:110s} calls={len(v)} median_ns={v[len(v) // 2]} min_ns={v[0]}")
 for sub in ('sq', 'sqf', 'fetch', 'write'):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in find(sub, '*counter_collection.csv'):
