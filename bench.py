@@ -452,6 +452,8 @@ def main():
                 roofline['valu_issue_frac'] = valu_wave_iter * 4 * waves * (args.steps / launches) / (SIMDS * kernel_ms * 1e-3 * CLOCK_HZ)
             roofline['note'] = ('k iterations per launch keep the profiles in registers: HBM traffic per launch (traffic) is that of ONE '
                                 'iteration, so the HBM roofline does not bound this kernel; achieved = executed fp64 operations / kernel time')
+            roofline['counts_source'] = ('instruction counts per wavefront and iteration and HBM bytes per launch: rocprofv3 counter passes over '
+                                         'this command, committed in profiles/traffic.json (not collected in this run); kernel_ms: HIP events, this run')
             k1_achieved = bytes_per_iter / (k1_max * 1e-3) / 1e9
             hbm_k1 = {'bound': 'hbm', 'achieved': k1_achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': k1_achieved / HBM_PEAK_GBS,
                       'traffic': committed(f'{tag}_k1_hbm_bytes_per_launch'), 'kernel': 'picard_1f_kernel (single-iteration form)',
