@@ -1103,6 +1103,8 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
             for (int i = 0; i < P; ++i) ue[i] = u[i + 1];
         }
     }
+    double face0 = lane_first ? 0.0 : 0.5;
+    landed(face0);
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) {
         if constexpr (!MULTI && !PACKED) done = false;
@@ -1382,8 +1384,9 @@ picard_1f_kernel(tg_state_1f S_, tg_params_1f Q) {
         for (int attempt = 0;; ++attempt) {
         ChunkElim<P, DIV> el;
         double mx = 0.0, ss = 0.0;
-        double hm2 = lane_first ? 0.0 : (h2l + h2first) / 2.0;
-        double hm3 = lane_first ? 0.0 : (h3l + h3first) / 2.0;
+        // (the face left of the first point does not exist: its values are zeros, here through the factor, 1/2 or 0, that
+        // the lane keeps; halving by a product is exact)
+        double hm2 = (h2l + h2first) * face0, hm3 = (h3l + h3first) * face0;
         double bm = 0.5;
         if (!half_everywhere) bm = fbeta_point<DIV>(hm2, hm3, rc.dx);     // a branch the whole wavefront takes or skips
         double h2c = h2first, h3c = h3first;
