@@ -1553,12 +1553,12 @@ struct Picard1fLauncher {
         int grid, block;
         size_t lds;
         geometry<G>(nb, grid, block, lds);
-        if (!G::kBlock && G::T == 64 && q->iters_per_launch > 1) {
+        if (!G::kBlock && q->iters_per_launch > 1) {
             // A wavefront that keeps a profile for many iterations lives long; alone in its workgroup it hands its slot and
             // its LDS tiles to the next one when IT is done, not when the slowest of four is (+1 % at 20 iterations per
             // launch; the single-iteration form is 2-3 % slower that way and keeps four wavefronts per workgroup)
             block = 64;
-            grid = (int)nb;
+            grid = (int)((nb + 64 / G::T - 1) / (64 / G::T));
         }
         uintptr_t al = reinterpret_cast<uintptr_t>(st->u) | reinterpret_cast<uintptr_t>(st->um1) |
                        reinterpret_cast<uintptr_t>(st->uE) | reinterpret_cast<uintptr_t>(st->DE) |
